@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Run in the build container only (the reference lives at /root/reference and
+never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+It imports the reference's own ``shard`` package read-only, feeds it seeded
+inputs (regenerable from ``tests/golden/inputs.py``) and stores the outputs as
+small safetensors files plus one JSON manifest.  Fixtures are data only: no
+reference source text is stored.
+"""
+import asyncio
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+from unittest.mock import AsyncMock, patch
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("golden_inputs", REPO / "tests" / "golden" / "inputs.py")
+gi = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gi)
+
+import shard.tensor.functions as ref_fn  # noqa: E402  (the reference)
+from shard.config import MergeConfig, MergeModel  # noqa: E402
+from shard.download import DownloadManager  # noqa: E402
+from shard.index import HFMultiModelIndex  # noqa: E402
+from shard.merge.fast_fourier import FourierMerge  # noqa: E402
+from shard.writer import ShardLayer  # noqa: E402
+
+OUT = REPO / "tests" / "golden"
+torch.set_num_threads(8)
+
+
+def cplx(store, key, z):
+    store[key + ".re"] = z.real.contiguous().clone()
+    store[key + ".im"] = z.imag.contiguous().clone()
+
+
+def gen_fft(manifest):
+    store = {}
+    for case in gi.FFT_CASES:
+        x = gi.fft_input(case)
+        f = ref_fn.fft_transform(x, "cpu")
+        cplx(store, f"{case['id']}.fft", f)
+        store[f"{case['id']}.ifft"] = ref_fn.ifft_transform(f, "cpu").contiguous().clone()
+        manifest["inputs"][case["id"]] = gi.checksum(x)
+    save_file(store, str(OUT / "g1_fft.safetensors"))
+
+
+def gen_interp(manifest):
+    store = {}
+    for case in gi.INTERP_CASES:
+        a, b = gi.pair_input(case)
+        fa = ref_fn.fft_transform(a, "cpu")
+        fb = ref_fn.fft_transform(b, "cpu")
+        r = ref_fn.interpolate_fft_components(
+            fa, fb, t=case["t"], device="cpu", t_sum=case["t_sum"],
+            cutoff_pct=case["cutoff"], cull_pct=case["cull"], interp_imag=case["imag"])
+        cplx(store, case["id"], r)
+        manifest["inputs"][case["id"]] = gi.checksum(a) + gi.checksum(b)
+    save_file(store, str(OUT / "g2_interp.safetensors"))
+
+
+def gen_slerp(manifest):
+    store = {}
+    for case in gi.SLERP_CASES:
+        a, b = gi.pair_input(case)
+        store[case["id"]] = ref_fn.slerp(a, b, case["t"]).contiguous().clone()
+        manifest["inputs"][case["id"]] = gi.checksum(a) + gi.checksum(b)
+    save_file(store, str(OUT / "g3_slerp.safetensors"))
+
+
+def gen_pair(manifest):
+    store = {}
+    meta = {}
+    for case in gi.PAIR_CASES:
+        a, b = gi.pair_input(case)
+        m, n0, n1 = ref_fn.merge_tensors_fft2_slerp(
+            a, b, t=case["t"], device="cpu", b=case["b"], t_sum=case["t_sum"],
+            cutoff_pct=case["cutoff"], cull_pct=case["cull"])
+        store[case["id"]] = m.contiguous().clone()
+        meta[case["id"]] = {"n0": n0, "n1": n1}
+        manifest["inputs"][case["id"]] = gi.checksum(a) + gi.checksum(b)
+    for case in gi.ARITH_CASES:
+        a, b = gi.pair_input(case)
+        m = ref_fn.task_arithmetic_fft2(a, b, t=case["t"], device="cpu", agreement=case["agreement"])
+        store[case["id"]] = m.contiguous().clone()
+        manifest["inputs"][case["id"]] = gi.checksum(a) + gi.checksum(b)
+    save_file(store, str(OUT / "g4_pair.safetensors"))
+    manifest["pair_meta"] = meta
+
+
+def gen_pairs_sched(manifest):
+    out = {}
+    for case in gi.SCHED_CASES:
+        corr = gi.sched_matrix(case)
+        out[case["id"]] = [[int(x), int(y), float(c)] for x, y, c in ref_fn.correlated_pairs(corr, case["way"])]
+    manifest["sched"] = out
+
+
+def run_ref_layer(case, tmp):
+    """Drive the reference FourierMerge._merge_layer with faked tensor loads
+    (same pattern as the reference's tests/merge/test_fast_fourier.py:299-316)."""
+    tensors, models, cfg_kw, layer_name = gi.layer_inputs(case)
+    cfg = MergeConfig(
+        finetune_merge=[MergeModel(**m) for m in models],
+        output_base_model=cfg_kw["output_base_model"],
+        output_dir=str(Path(tmp) / "out"), device="cpu",
+        cache_dir=str(Path(tmp) / f"cache_{case['id']}"), storage_dir=str(Path(tmp) / "storage"))
+    idx = HFMultiModelIndex(download_manager=DownloadManager(storage_path=Path(tmp) / "storage"),
+                            cache_path=Path(tmp) / "cache_idx")
+    merger = FourierMerge(config=cfg, index_manager=idx)
+
+    def fake_get(model_uri, tensor_name, device="cpu"):
+        p = AsyncMock()
+        p.get = AsyncMock(return_value=tensors[model_uri])
+        return p
+
+    sl = ShardLayer(layer_order_idx=1, shard_name="model-00001.safetensors", layer_name=layer_name, written=False)
+
+    async def go():
+        with patch.object(idx, "get_tensor", side_effect=fake_get):
+            with patch.object(idx, "preload_tensor", new_callable=AsyncMock):
+                return await merger._merge_layer(sl, device="cpu")
+
+    return asyncio.run(go())
+
+
+def gen_layers(manifest):
+    store = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for case in gi.LAYER_CASES:
+            out = run_ref_layer(case, tmp)
+            store[case["id"]] = out.contiguous().clone()
+            tensors, _, _, _ = gi.layer_inputs(case)
+            manifest["inputs"][case["id"]] = sum((gi.checksum(v) for v in tensors.values()), [])
+    save_file(store, str(OUT / "g7_layer.safetensors"))
+
+
+def gen_cli(manifest):
+    """G8: the reference CLI end to end on a tiny local model."""
+    from click.testing import CliRunner
+    from safetensors import safe_open
+    from shard.__main__ import cli
+    store = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg_path = gi.write_cli_model(Path(tmp))
+        res = CliRunner().invoke(cli, ["merge", str(cfg_path), "--cache-dir", str(Path(tmp) / "cache")])
+        assert res.exit_code == 0, res.output
+        out_dir = Path(tmp) / "merged"
+        for shard_file in sorted(out_dir.glob("*.safetensors")):
+            with safe_open(str(shard_file), framework="pt") as f:
+                for k in f.keys():
+                    store[f"{shard_file.name}::{k}"] = f.get_tensor(k).contiguous().clone()
+        manifest["cli"] = {
+            "files": sorted(p.name for p in out_dir.iterdir()),
+            "index": json.load(open(out_dir / "model.safetensors.index.json")),
+            "readme": (out_dir / "README.md").read_text(),
+        }
+    save_file(store, str(OUT / "g8_cli.safetensors"))
+
+
+def main():
+    manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "inputs": {}}
+    gen_fft(manifest)
+    gen_interp(manifest)
+    gen_slerp(manifest)
+    gen_pair(manifest)
+    gen_pairs_sched(manifest)
+    gen_layers(manifest)
+    gen_cli(manifest)
+    with open(OUT / "manifest.json", "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    total = sum(p.stat().st_size for p in OUT.glob("*.safetensors"))
+    print(f"golden written: {total/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

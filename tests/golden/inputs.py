@@ -1,0 +1,226 @@
+"""Seeded inputs for the golden vectors (shared by oracle/gen_golden.py, which
+runs the reference on them, and by the tests, which run the oracle and the HIP
+path on them).  Pure torch; imports neither the reference nor the oracle."""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import torch
+
+GOLDEN_DIR = Path(__file__).resolve().parent
+
+
+def _randn(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def checksum(x: torch.Tensor) -> List[float]:
+    d = x.double()
+    return [float(d.sum()), float(d.abs().sum())]
+
+
+# ---- G1: transforms -------------------------------------------------------
+FFT_CASES = [
+    {"id": "fft_1d_96", "shape": (96,), "seed": 11},
+    {"id": "fft_1d_4096", "shape": (4096,), "seed": 12},
+    {"id": "fft_2d_128x256", "shape": (128, 256), "seed": 13},
+    {"id": "fft_2d_8x512", "shape": (8, 512), "seed": 14},
+    {"id": "fft_2d_448x64", "shape": (448, 64), "seed": 15},
+    {"id": "fft_2d_56x112", "shape": (56, 112), "seed": 16},
+    {"id": "fft_2d_96x160", "shape": (96, 160), "seed": 17},
+    {"id": "fft_2d_3x3", "shape": (3, 3), "seed": 18},
+    {"id": "fft_2d_1x64", "shape": (1, 64), "seed": 19},
+]
+
+
+def fft_input(case) -> torch.Tensor:
+    return _randn(case["shape"], case["seed"])
+
+
+# ---- G2/G3/G4/G5: pair-level functions -----------------------------------
+def pair_input(case) -> Tuple[torch.Tensor, torch.Tensor]:
+    a = _randn(case["shape"], case["seed"], case.get("sa", 0.003))
+    b = _randn(case["shape"], case["seed"] + 7, case.get("sb", 0.002))
+    mix = case.get("mix", 0.0)         # correlated pairs make the slerp class non-trivial
+    if mix:
+        b = b + mix * a
+    if case.get("zero_b"):
+        b = torch.zeros_like(b)
+    if case.get("zero_a"):
+        a = torch.zeros_like(a)
+    return a, b
+
+
+INTERP_CASES = [
+    {"id": "interp_plain", "shape": (128, 128), "seed": 21, "t": 0.5, "t_sum": 1.0, "cutoff": 0.0, "cull": 0.0, "imag": True},
+    {"id": "interp_cut_cull", "shape": (128, 128), "seed": 22, "t": 0.357, "t_sum": 1.0, "cutoff": 0.08, "cull": 0.2, "imag": True, "mix": 0.5},
+    {"id": "interp_noimag", "shape": (128, 128), "seed": 23, "t": 0.5, "t_sum": 0.7, "cutoff": 0.08, "cull": 0.1, "imag": False},
+    {"id": "interp_1d", "shape": (2048,), "seed": 24, "t": 0.625, "t_sum": 1.0, "cutoff": 0.08, "cull": 0.2, "imag": True, "mix": 0.3},
+]
+
+SLERP_CASES = [
+    {"id": "slerp_1000", "shape": (1000,), "seed": 31, "t": 0.3, "sa": 1.0, "sb": 1.0, "mix": 0.8},
+    {"id": "slerp_t0", "shape": (257,), "seed": 32, "t": 0.0, "sa": 1.0, "sb": 1.0},
+    {"id": "slerp_t1", "shape": (257,), "seed": 33, "t": 1.0, "sa": 2.0, "sb": 0.5, "mix": 0.2},
+]
+
+_P = {"b": 0.1, "t_sum": 1.0}
+PAIR_CASES = [
+    dict(_P, id="pair_256", shape=(256, 256), seed=41, t=0.375, cutoff=0.08, cull=0.2),
+    dict(_P, id="pair_256_mix", shape=(256, 256), seed=42, t=0.5, cutoff=0.08, cull=0.1, mix=0.6),
+    dict(_P, id="pair_96x160", shape=(96, 160), seed=43, t=0.5, cutoff=0.08, cull=0.2),
+    dict(_P, id="pair_448x64", shape=(448, 64), seed=44, t=0.6, cutoff=0.08, cull=0.2, mix=0.2),
+    dict(_P, id="pair_8x512", shape=(8, 512), seed=45, t=0.5, cutoff=0.08, cull=0.2),
+    dict(_P, id="pair_1d_4096", shape=(4096,), seed=46, t=0.5, cutoff=0.08, cull=0.2),
+    dict(_P, id="pair_1d_96", shape=(96,), seed=47, t=0.25, cutoff=0.08, cull=0.2),
+    dict(_P, id="pair_nocut", shape=(64, 64), seed=48, t=0.5, cutoff=0.0, cull=0.0),
+    dict(_P, id="pair_small_n1", shape=(64, 64), seed=49, t=0.5, cutoff=0.08, cull=0.2, sb=1e-8),
+    dict(_P, id="pair_small_n0", shape=(64, 64), seed=50, t=0.5, cutoff=0.08, cull=0.2, sa=1e-8, sb=1.0),
+    dict(_P, id="pair_ratio_lt_b", shape=(64, 64), seed=51, t=0.5, cutoff=0.08, cull=0.2, sa=1.0, sb=0.01),
+    dict(_P, id="pair_zero_b", shape=(32, 32), seed=52, t=0.5, cutoff=0.08, cull=0.2, zero_b=True),
+]
+
+ARITH_CASES = [
+    {"id": "arith_agree", "shape": (128, 128), "seed": 61, "t": 1.0, "agreement": True},
+    {"id": "arith_noagree", "shape": (128, 128), "seed": 62, "t": 0.5, "agreement": False},
+    {"id": "arith_tiny_b", "shape": (64, 96), "seed": 63, "t": 1.0, "agreement": True, "sa": 1.0, "sb": 1e-6},
+    {"id": "arith_1d", "shape": (1024,), "seed": 64, "t": 1.0, "agreement": True},
+]
+
+# ---- G6: pairing ----------------------------------------------------------
+SCHED_CASES = [
+    {"id": "sched_k2", "norms": [3.0, 2.0], "way": "least"},
+    {"id": "sched_k3", "norms": [3.0, 2.0, 5.0], "way": "least"},
+    {"id": "sched_k4", "norms": [3.0, 2.0, 5.0, 4.0], "way": "least"},
+    {"id": "sched_k5", "norms": [1.5, 0.25, 4.0, 2.0, 3.0], "way": "least"},
+    {"id": "sched_k4_ties", "norms": [2.0, 2.0, 2.0, 2.0], "way": "least"},
+    {"id": "sched_k4_most", "norms": [3.0, 2.0, 5.0, 4.0], "way": "most"},
+    {"id": "sched_k3_zero", "norms": [0.0, 1.0, 2.0], "way": "least"},
+]
+
+
+def sched_matrix(case) -> torch.Tensor:
+    v = torch.tensor(case["norms"], dtype=torch.float32)
+    k = len(v)
+    m = torch.zeros((k, k), dtype=torch.float32)
+    for i in range(k):
+        for j in range(i + 1, k):
+            m[i, j] = v[i] * v[j]
+    return m
+
+
+# ---- G7: whole-layer cases ------------------------------------------------
+SIG = (0.002, 0.003, 0.0025, 0.004)
+ALPHA = (0.3, 0.5, 0.2, 0.4)
+LAYER_CASES = [
+    {"id": "layer_k1", "shape": (128, 128), "seed": 100, "k": 1},
+    {"id": "layer_k2", "shape": (256, 256), "seed": 110, "k": 2},
+    {"id": "layer_k3", "shape": (256, 256), "seed": 120, "k": 3},
+    {"id": "layer_k4", "shape": (256, 256), "seed": 130, "k": 4},
+    {"id": "layer_k2_rect", "shape": (448, 128), "seed": 140, "k": 2},
+    {"id": "layer_k2_1d", "shape": (4096,), "seed": 150, "k": 2},
+    {"id": "layer_k2_arith", "shape": (128, 128), "seed": 160, "k": 2, "sig": (0.003, 1e-5)},
+    {"id": "layer_k2_add", "shape": (64, 64), "seed": 170, "k": 2, "same": True},
+    {"id": "layer_k3_window", "shape": (128, 128), "seed": 180, "k": 3, "layer": 5,
+     "window": {1: {"start_layer": 6}, 2: {"end_layer": 7}}},
+    {"id": "layer_k2_twobases", "shape": (128, 128), "seed": 190, "k": 2, "own_base": True},
+    {"id": "layer_k3_swap", "shape": (128, 256), "seed": 200, "k": 3, "sig": (0.001, 0.004, 0.002)},
+]
+
+
+def layer_inputs(case):
+    """-> (tensors by model uri, MergeModel kwargs list, config kwargs, layer name)"""
+    shape, seed, k = case["shape"], case["seed"], case["k"]
+    sig = case.get("sig", SIG)
+    base = _randn(shape, seed, 0.02).to(torch.bfloat16)
+    tensors: Dict[str, torch.Tensor] = {"org/base": base}
+    models = []
+    for i in range(k):
+        b_uri = "org/base"
+        b_t = base
+        if case.get("own_base") and i == 1:
+            b_uri = "org/base2"
+            b_t = (base.float() + _randn(shape, seed + 50, 0.001)).to(torch.bfloat16)
+            tensors[b_uri] = b_t
+        if case.get("same"):
+            ft = b_t.clone()
+        else:
+            ft = (b_t.float() + _randn(shape, seed + 1 + i, sig[i % len(sig)])).to(torch.bfloat16)
+        uri = f"org/ft{i}"
+        tensors[uri] = ft
+        kw = {"model": uri, "base": b_uri, "alpha": ALPHA[i % 4]}
+        kw.update(case.get("window", {}).get(i, {}))
+        models.append(kw)
+    layer = case.get("layer", 0)
+    return tensors, models, {"output_base_model": "org/base"}, f"model.layers.{layer}.self_attn.q_proj.weight"
+
+
+# ---- G8: a tiny model on disk for the CLI ----------------------------------
+CLI_TENSORS = [
+    ("model.embed_tokens.weight", (64, 64)),
+    ("model.layers.0.self_attn.q_proj.weight", (128, 128)),
+    ("model.layers.0.input_layernorm.weight", (128,)),
+    ("model.layers.1.self_attn.q_proj.weight", (128, 128)),
+    ("model.layers.1.input_layernorm.weight", (128,)),
+    ("model.norm.weight", (64,)),
+    ("lm_head.weight", (64, 64)),
+]
+CLI_SHARDS = {
+    "model-00001-of-00002.safetensors": CLI_TENSORS[:3],
+    "model-00002-of-00002.safetensors": CLI_TENSORS[3:],
+}
+
+
+def cli_model_tensors(which: int) -> Dict[str, torch.Tensor]:
+    """which = 0 -> base, 1.. -> finetunes."""
+    out = {}
+    for ti, (name, shape) in enumerate(CLI_TENSORS):
+        base = _randn(shape, 900 + ti, 0.02).to(torch.bfloat16)
+        if which == 0:
+            out[name] = base
+        else:
+            out[name] = (base.float() + _randn(shape, 900 + 100 * which + ti, SIG[which - 1])).to(torch.bfloat16)
+    return out
+
+
+def write_cli_model(root: Path, n_ft: int = 2, device: str = "cpu") -> Path:
+    """Lay out {storage}/org/{base,ft1,..}/ with shards + index, and a config."""
+    from safetensors.torch import save_file
+    storage = root / "storage"
+    uris = ["org/base"] + [f"org/ft{i}" for i in range(1, n_ft + 1)]
+    for which, uri in enumerate(uris):
+        d = storage / uri
+        d.mkdir(parents=True, exist_ok=True)
+        tens = cli_model_tensors(which)
+        weight_map = {}
+        for shard, items in CLI_SHARDS.items():
+            save_file({n: tens[n] for n, _ in items}, str(d / shard), metadata={"format": "pt"})
+            for n, _ in items:
+                weight_map[n] = shard
+        with open(d / "model.safetensors.index.json", "w") as f:
+            json.dump({"metadata": {"total_size": 0}, "weight_map": weight_map}, f)
+    cfg = {
+        "output_base_model": "org/base",
+        "finetune_merge": [
+            {"model": f"org/ft{i}", "base": "org/base", "alpha": ALPHA[i - 1], "is_input": i == 1}
+            for i in range(1, n_ft + 1)
+        ],
+        "output_dir": str(root / "merged"),
+        "output_dtype": "bfloat16",
+        "device": device,
+        "cache_dir": str(root / "cache"),
+        "storage_dir": str(storage),
+    }
+    import yaml
+    p = root / "merge.yaml"
+    with open(p, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return p
+
+
+def load_manifest() -> dict:
+    with open(GOLDEN_DIR / "manifest.json") as f:
+        return json.load(f)
