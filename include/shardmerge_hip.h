@@ -1,0 +1,136 @@
+/* shardmerge_hip.h - C ABI of the MI355X-native spectral-merge hot path.
+ *
+ * This is the drop-in boundary for shardmerge's per-layer merge
+ * (reference: shard/merge/fast_fourier.py:103-276 calling
+ * shard/tensor/functions.py:24-302).  Every pointer marked "device" is a HIP
+ * device pointer (e.g. torch.Tensor.data_ptr() on PyTorch-ROCm); `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  The library borrows
+ * input pointers for the duration of a call, never mutates inputs, writes only
+ * into caller-provided outputs and owns nothing but its internal workspace
+ * (grown on demand with hipMalloc, reused across calls).  One context serves
+ * one caller thread / one device.
+ *
+ * All functions return SMHIP_OK (0) or an error code; smhip_last_error() gives
+ * the message.  The Python wrapper maps SMHIP_ERR_INF_IFFT / _INF_MERGED to the
+ * reference's ValueError texts (functions.py:217, fast_fourier.py:274).
+ */
+#ifndef SHARDMERGE_HIP_H
+#define SHARDMERGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smhip_ctx smhip_ctx;
+
+enum {
+    SMHIP_OK = 0,
+    SMHIP_ERR_HIP = 1,         /* a HIP runtime call failed */
+    SMHIP_ERR_SHAPE = 2,       /* unsupported shape (length with a prime factor > 13, or > 32768) */
+    SMHIP_ERR_INF_IFFT = 3,    /* "Inf in ifft output"            (functions.py:215-217) */
+    SMHIP_ERR_INF_MERGED = 4,  /* "Inf in merged tensor for ..."  (fast_fourier.py:273-274) */
+    SMHIP_ERR_ARG = 5,
+    SMHIP_ERR_NOMEM = 6
+};
+
+enum { SMHIP_BF16 = 0, SMHIP_F16 = 1, SMHIP_F32 = 2 };
+
+/* branch taken by a pair merge (fast_fourier.py:223 / :226 / :233) */
+enum { SMHIP_BRANCH_ADD = 0, SMHIP_BRANCH_ARITH = 1, SMHIP_BRANCH_SLERP = 2, SMHIP_BRANCH_CARRY = 3,
+       SMHIP_BRANCH_EARLY_V0 = 4 /* functions.py:184-190 */, SMHIP_BRANCH_LINEAR = 5 /* functions.py:199-202 */ };
+
+#define SMHIP_MAX_MODELS 16
+#define SMHIP_MAX_PAIRS 32
+
+/* ---- lifetime ---------------------------------------------------------- */
+int smhip_create(int device, smhip_ctx** out);
+void smhip_destroy(smhip_ctx* ctx);
+const char* smhip_last_error(smhip_ctx* ctx);
+const char* smhip_version(void);
+/* pre-size the workspace for [rows x cols] tensors (optional; it grows on demand) */
+int smhip_reserve(smhip_ctx* ctx, int rows, int cols);
+size_t smhip_workspace_bytes(smhip_ctx* ctx);
+/* 0 if a length-n transform is supported, SMHIP_ERR_SHAPE otherwise */
+int smhip_length_supported(int n);
+
+/* ---- A4 / A8: transforms (reference fft_transform / ifft_transform,
+ *      functions.py:45-73).  x: device float[rows*cols] (rows = 1 for 1-D);
+ *      spectrum: device interleaved complex64 [rows][cols]. ------------------- */
+int smhip_fft_transform(smhip_ctx* ctx, const float* x, int rows, int cols, float* spectrum, void* stream);
+int smhip_ifft_transform(smhip_ctx* ctx, const float* spectrum, int rows, int cols, float* real_out, void* stream);
+
+/* ---- A5-A7: spectrum-level blends on full complex spectra
+ *      (interpolate_fft_components functions.py:90-162,
+ *       arithmetic_fft_components functions.py:256-302). --------------------- */
+typedef struct {
+    double cutoff_threshold, cull_threshold;
+    double dot, s00, s01, s11;
+    uint64_t n_slerp;
+} smhip_blend_info;
+int smhip_interpolate_fft_components(smhip_ctx* ctx, const float* f0, const float* f1, int rows, int cols,
+                                     double t, double t_sum, double cutoff_pct, double cull_pct, int interp_imag,
+                                     float* out_spectrum, smhip_blend_info* info, void* stream);
+int smhip_arithmetic_fft_components(smhip_ctx* ctx, const float* f0, const float* f1, int rows, int cols,
+                                    double t, int agreement, int do_imag, float* out_spectrum, void* stream);
+
+/* ---- A9: merge_tensors_fft2_slerp (functions.py:164-221).
+ *      v0, v1, out: device float[rows*cols].  *branch reports which path ran
+ *      (SLERP, EARLY_V0 or LINEAR). ------------------------------------------ */
+int smhip_merge_tensors_fft2_slerp(smhip_ctx* ctx, const float* v0, const float* v1, int rows, int cols,
+                                   double t, double b, double t_sum, double cutoff_pct, double cull_pct,
+                                   float* out, double* norm0, double* norm1, int* branch,
+                                   smhip_blend_info* info, void* stream);
+
+/* ---- A10: task_arithmetic_fft2 (functions.py:224-254) ------------------- */
+int smhip_task_arithmetic_fft2(smhip_ctx* ctx, const float* v0, const float* v1, int rows, int cols,
+                               double t, int agreement, float* out, void* stream);
+
+/* ---- A1-A13 fused: the block-tensor branch of FourierMerge._merge_layer
+ *      (fast_fourier.py:132-276 + base.py:117-137). ------------------------- */
+typedef struct {
+    int k;                                  /* models that pass use_layer_index */
+    const void* finetune[SMHIP_MAX_MODELS]; /* device, in_dtype, [rows*cols] */
+    const void* base[SMHIP_MAX_MODELS];     /* device, in_dtype: each model's own base */
+    double alpha[SMHIP_MAX_MODELS];
+    int in_dtype;
+    const void* base_out;                   /* device: output_base_model's tensor */
+    int base_out_dtype;
+    int rows, cols;                         /* rows = 1 for 1-D tensors */
+    double target_norm_offset;              /* 1e-10 */
+    double cull_start_pct;                  /* 0.20 */
+    double cutoff_pct;                      /* 0.08 */
+    double t_sum;                           /* 1.0  */
+} smhip_layer_desc;
+
+typedef struct {
+    double target_norm;
+    double delta_norm[SMHIP_MAX_MODELS];
+    int n_steps;                            /* pair merges + carries, in order */
+    int step_x[SMHIP_MAX_PAIRS], step_y[SMHIP_MAX_PAIRS];   /* stack indices (y = -1: carry) */
+    int step_branch[SMHIP_MAX_PAIRS];
+    smhip_blend_info step_info[SMHIP_MAX_PAIRS];
+    uint32_t nan_ifft, nan_final;           /* NaNs replaced by 0 (functions.py:211-213, fast_fourier.py:270-271) */
+    double merged_delta_norm;               /* || result before add-back || when available, else -1 */
+} smhip_layer_report;
+
+/* out: device bf16 [rows*cols] (the reference hard-casts block tensors to bf16,
+ * fast_fourier.py:276).  delta_out (optional, may be NULL): device float of the
+ * merged delta before add-back, for parity checks. */
+int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf16, float* delta_out,
+                      smhip_layer_report* report, void* stream);
+
+/* ---- profiling: per-kernel device time measured with HIP events on the
+ *      caller's stream (bench.py's roofline leg) ---------------------------- */
+int smhip_profile_enable(smhip_ctx* ctx, int on);
+int smhip_profile_reset(smhip_ctx* ctx);
+int smhip_profile_count(smhip_ctx* ctx);
+/* i-th kernel: name, number of launches, total milliseconds */
+int smhip_profile_get(smhip_ctx* ctx, int i, const char** name, uint64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHARDMERGE_HIP_H */

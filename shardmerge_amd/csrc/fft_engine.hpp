@@ -1,0 +1,319 @@
+// fft_engine.hpp - work-group FFT engine for gfx950 (MI355X).
+//
+// One FFT of length N is computed by a group of T threads (T a multiple of the
+// 64-lane wavefront).  The data lives in REGISTERS (<= EMAX complex values per
+// thread, i.e. the 512 KB register file of a CU is the working store, not the
+// 160 KB LDS); between Stockham radix passes the values are exchanged through
+// LDS one component (re, then im) at a time, so an N-point transform needs only
+// 4*N bytes of LDS (+1/32 padding against bank conflicts).
+//
+// Everything here is written once and compiled twice: by hipcc for the GPU and
+// by g++ for the CPU work-group emulator used by the "not gpu" tests
+// (tests/emul).  No torch, no rocFFT.
+#pragma once
+#include <cstdint>
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SM_HD __host__ __device__ __forceinline__
+#else
+#define SM_HD inline
+#endif
+#define SM_CONST static constexpr
+
+namespace smhip {
+
+#include "twiddle_consts.inc"
+
+constexpr int EMAX = 32;        // complex values a thread may hold in a pass
+constexpr int EREG = EMAX + 4;  // register array length (storers need a little slack)
+constexpr int MAX_PASSES = 8;
+
+struct cf2 { float x, y; };
+
+// plan of one N-point transform, passed to kernels by value
+struct FftPlanDev {
+    int N;                 // transform length
+    int T;                 // threads per transform (multiple of 64)
+    int npass;
+    int radix[MAX_PASSES];
+    const cf2* tw;         // tw[j] = exp(-2*pi*i*j/N), j < N (device memory)
+    int lds_floats;        // padded LDS floats per transform
+};
+
+template <int I, int N, class F>
+SM_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// LDS padding: one spare word per 32 breaks the power-of-two strides of the
+// radix scatters (stride-16 words would otherwise be a 16-way bank conflict).
+SM_HD int lpad(int o) { return o + (o >> 5); }
+
+// ---- multiply by W32^E (compile-time exponent) --------------------------------
+template <int E>
+SM_HD void mul_w32(float& r, float& i) {
+    constexpr int e = ((E % 32) + 32) % 32;
+    if constexpr (e == 0) {
+    } else if constexpr (e == 8) {          // * (-i)
+        float t = r; r = i; i = -t;
+    } else if constexpr (e == 16) {
+        r = -r; i = -i;
+    } else if constexpr (e == 24) {         // * (+i)
+        float t = r; r = -i; i = t;
+    } else {
+        constexpr float c = W32_RE[e];
+        constexpr float s = W32_IM[e];
+        float t = r * c - i * s;
+        i = r * s + i * c;
+        r = t;
+    }
+}
+
+// ---- small in-register DFTs (forward, natural order in and out) ----------------
+template <int R> struct Dft;
+
+template <> struct Dft<1> { static SM_HD void run(float*, float*) {} };
+
+template <> struct Dft<2> {
+    static SM_HD void run(float* re, float* im) {
+        float ar = re[0], ai = im[0];
+        re[0] = ar + re[1]; im[0] = ai + im[1];
+        re[1] = ar - re[1]; im[1] = ai - im[1];
+    }
+};
+
+template <> struct Dft<4> {
+    static SM_HD void run(float* re, float* im) {
+        float t0r = re[0] + re[2], t0i = im[0] + im[2];
+        float t1r = re[0] - re[2], t1i = im[0] - im[2];
+        float t2r = re[1] + re[3], t2i = im[1] + im[3];
+        float dr = re[1] - re[3], di = im[1] - im[3];
+        float t3r = di, t3i = -dr;                       // (x1-x3) * (-i)
+        re[0] = t0r + t2r; im[0] = t0i + t2i;
+        re[2] = t0r - t2r; im[2] = t0i - t2i;
+        re[1] = t1r + t3r; im[1] = t1i + t3i;
+        re[3] = t1r - t3r; im[3] = t1i - t3i;
+    }
+};
+
+// N = A*B Cooley-Tukey in registers: A-point DFTs over the slow index, twiddle,
+// B-point DFTs, outputs written to natural positions k1 + A*k2.
+template <int A, int B>
+struct DftComposite {
+    static SM_HD void run(float* re, float* im) {
+        constexpr int N = A * B;
+        float yr[N], yi[N];
+        static_for<0, B>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            float tr[A], ti[A];
+            static_for<0, A>([&](auto a_) {
+                constexpr int a = decltype(a_)::value;
+                tr[a] = re[B * a + b]; ti[a] = im[B * a + b];
+            });
+            Dft<A>::run(tr, ti);
+            static_for<0, A>([&](auto k_) {
+                constexpr int k1 = decltype(k_)::value;
+                float r = tr[k1], i = ti[k1];
+                mul_w32<(b * k1) * (32 / N)>(r, i);
+                yr[k1 * B + b] = r; yi[k1 * B + b] = i;
+            });
+        });
+        static_for<0, A>([&](auto k_) {
+            constexpr int k1 = decltype(k_)::value;
+            float tr[B], ti[B];
+            static_for<0, B>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                tr[b] = yr[k1 * B + b]; ti[b] = yi[k1 * B + b];
+            });
+            Dft<B>::run(tr, ti);
+            static_for<0, B>([&](auto k2_) {
+                constexpr int k2 = decltype(k2_)::value;
+                re[k1 + A * k2] = tr[k2]; im[k1 + A * k2] = ti[k2];
+            });
+        });
+    }
+};
+
+template <> struct Dft<8> { static SM_HD void run(float* re, float* im) { DftComposite<2, 4>::run(re, im); } };
+template <> struct Dft<16> { static SM_HD void run(float* re, float* im) { DftComposite<4, 4>::run(re, im); } };
+template <> struct Dft<32> { static SM_HD void run(float* re, float* im) { DftComposite<4, 8>::run(re, im); } };
+
+template <int P> struct OddTab;
+template <> struct OddTab<3> { SM_HD static constexpr float c(int m) { return ODD3_COS[m]; } SM_HD static constexpr float s(int m) { return ODD3_SIN[m]; } };
+template <> struct OddTab<5> { SM_HD static constexpr float c(int m) { return ODD5_COS[m]; } SM_HD static constexpr float s(int m) { return ODD5_SIN[m]; } };
+template <> struct OddTab<7> { SM_HD static constexpr float c(int m) { return ODD7_COS[m]; } SM_HD static constexpr float s(int m) { return ODD7_SIN[m]; } };
+template <> struct OddTab<11> { SM_HD static constexpr float c(int m) { return ODD11_COS[m]; } SM_HD static constexpr float s(int m) { return ODD11_SIN[m]; } };
+template <> struct OddTab<13> { SM_HD static constexpr float c(int m) { return ODD13_COS[m]; } SM_HD static constexpr float s(int m) { return ODD13_SIN[m]; } };
+
+// odd prime P: X_k = P_k - i Q_k, X_{P-k} = P_k + i Q_k with
+// P_k = x0 + sum_j cos(2 pi j k / P)(x_j + x_{P-j}),  Q_k = sum_j sin(2 pi j k / P)(x_j - x_{P-j})
+template <int P>
+struct DftOdd {
+    static SM_HD void run(float* re, float* im) {
+        constexpr int H = (P - 1) / 2;
+        float sr[H + 1], si[H + 1], dr[H + 1], di[H + 1];
+        float x0r = re[0], x0i = im[0];
+        float accr = x0r, acci = x0i;
+        static_for<1, H + 1>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            sr[j] = re[j] + re[P - j]; si[j] = im[j] + im[P - j];
+            dr[j] = re[j] - re[P - j]; di[j] = im[j] - im[P - j];
+            accr += sr[j]; acci += si[j];
+        });
+        re[0] = accr; im[0] = acci;
+        static_for<1, H + 1>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            float pr = x0r, pi = x0i, qr = 0.f, qi = 0.f;
+            static_for<1, H + 1>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                constexpr float c = OddTab<P>::c((j * k) % P);
+                constexpr float s = OddTab<P>::s((j * k) % P);
+                pr += c * sr[j]; pi += c * si[j];
+                qr += s * dr[j]; qi += s * di[j];
+            });
+            re[k] = pr + qi; im[k] = pi - qr;
+            re[P - k] = pr - qi; im[P - k] = pi + qr;
+        });
+    }
+};
+template <> struct Dft<3> { static SM_HD void run(float* re, float* im) { DftOdd<3>::run(re, im); } };
+template <> struct Dft<5> { static SM_HD void run(float* re, float* im) { DftOdd<5>::run(re, im); } };
+template <> struct Dft<7> { static SM_HD void run(float* re, float* im) { DftOdd<7>::run(re, im); } };
+template <> struct Dft<11> { static SM_HD void run(float* re, float* im) { DftOdd<11>::run(re, im); } };
+template <> struct Dft<13> { static SM_HD void run(float* re, float* im) { DftOdd<13>::run(re, im); } };
+
+// radices the planner may use (keep in sync with plan_fft in smhip_host.cpp)
+#define SM_RADIX_SWITCH(r, ...)                                  \
+    switch (r) {                                                 \
+        case 1:  { constexpr int RX = 1;  __VA_ARGS__; } break;  \
+        case 2:  { constexpr int RX = 2;  __VA_ARGS__; } break;  \
+        case 3:  { constexpr int RX = 3;  __VA_ARGS__; } break;  \
+        case 4:  { constexpr int RX = 4;  __VA_ARGS__; } break;  \
+        case 5:  { constexpr int RX = 5;  __VA_ARGS__; } break;  \
+        case 7:  { constexpr int RX = 7;  __VA_ARGS__; } break;  \
+        case 8:  { constexpr int RX = 8;  __VA_ARGS__; } break;  \
+        case 11: { constexpr int RX = 11; __VA_ARGS__; } break;  \
+        case 13: { constexpr int RX = 13; __VA_ARGS__; } break;  \
+        case 16: { constexpr int RX = 16; __VA_ARGS__; } break;  \
+        case 32: { constexpr int RX = 32; __VA_ARGS__; } break;  \
+        default: break;                                          \
+    }
+
+// ---- Stockham pass pieces, per thread ---------------------------------------
+// Pass with radix R and sub-transform size Ns: butterfly j (0 <= j < N/R) reads
+// in[j + i*N/R], multiplies by W_{Ns*R}^{i*(j mod Ns)}, does an R-point DFT and
+// writes out[(j - j mod Ns)*R + (j mod Ns) + i*Ns].  Thread t owns butterflies
+// j = t + m*T; their values sit in x[m*R + i].
+
+template <int R>
+SM_HD void pass_gather(float* x, const float* lds, int N, int T, int t) {
+    constexpr int MB = EMAX / R;
+    const int nb = N / R;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int j = t + m * T;
+        if (j < nb) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) x[m * R + i] = lds[lpad(j + i * nb)];
+        }
+    }
+}
+
+template <int R>
+SM_HD void pass_scatter(const float* x, float* lds, int N, int Ns, int T, int t) {
+    constexpr int MB = EMAX / R;
+    const int nb = N / R;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int j = t + m * T;
+        if (j < nb) {
+            const int k = j % Ns;
+            const int base = (j - k) * R + k;
+#pragma unroll
+            for (int i = 0; i < R; ++i) lds[lpad(base + i * Ns)] = x[m * R + i];
+        }
+    }
+}
+
+template <int R>
+SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const cf2* tw) {
+    constexpr int MB = EMAX / R;
+    const int nb = N / R;
+    const int tstep = N / (Ns * R);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int j = t + m * T;
+        if (j < nb) {
+            if (Ns > 1) {
+                const int k = j % Ns;
+#pragma unroll
+                for (int i = 1; i < R; ++i) {
+                    const cf2 w = tw[i * k * tstep];
+                    const float r = xr[m * R + i], q = xi[m * R + i];
+                    xr[m * R + i] = r * w.x - q * w.y;
+                    xi[m * R + i] = r * w.y + q * w.x;
+                }
+            }
+            Dft<R>::run(xr + m * R, xi + m * R);
+        }
+    }
+}
+
+// Run a whole transform for every group of a work-group.
+//   nat_scatter(tid, state, comp): write the loaded, natural-order values of
+//        component comp (0 = re, 1 = im) into LDS (element n of group g at
+//        lds + g*lds_floats + lpad(n)).
+//   fin_gather(tid, state, comp): read from LDS (natural order X[k]) what the
+//        storer needs of component comp.
+// State must expose float xr[EREG], xi[EREG].
+template <class Ex, class StT, class NatScatter, class FinGather>
+SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
+    using S = typename StT::value_type;
+    const int N = pl.N, T = pl.T;
+    // natural -> first pass layout, one component at a time
+    for (int comp = 0; comp < 2; ++comp) {
+        ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp); });
+        ex.sync();
+        ex.each(st, [&](int tid, S& s) {
+            float* x = comp ? s.xi : s.xr;
+            const float* l = lds + (tid / T) * pl.lds_floats;
+            SM_RADIX_SWITCH(pl.radix[0], pass_gather<RX>(x, l, N, T, tid % T));
+        });
+        ex.sync();
+    }
+    int Ns = 1;
+    for (int p = 0; p < pl.npass; ++p) {
+        const int r = pl.radix[p];
+        ex.each(st, [&](int tid, S& s) {
+            SM_RADIX_SWITCH(r, pass_compute<RX>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw));
+        });
+        const bool last = (p + 1 == pl.npass);
+        for (int comp = 0; comp < 2; ++comp) {
+            ex.each(st, [&](int tid, S& s) {
+                const float* x = comp ? s.xi : s.xr;
+                float* l = lds + (tid / T) * pl.lds_floats;
+                SM_RADIX_SWITCH(r, pass_scatter<RX>(x, l, N, Ns, T, tid % T));
+            });
+            ex.sync();
+            if (!last) {
+                const int rn = pl.radix[p + 1];
+                ex.each(st, [&](int tid, S& s) {
+                    float* x = comp ? s.xi : s.xr;
+                    const float* l = lds + (tid / T) * pl.lds_floats;
+                    SM_RADIX_SWITCH(rn, pass_gather<RX>(x, l, N, T, tid % T));
+                });
+            } else {
+                ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp); });
+            }
+            ex.sync();
+        }
+        Ns *= r;
+    }
+}
+
+}  // namespace smhip

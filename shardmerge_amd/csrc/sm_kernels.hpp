@@ -1,0 +1,1193 @@
+// sm_kernels.hpp - bodies of every kernel of the spectral-merge pipeline.
+//
+// Each body is a template over an execution policy `Ex`:
+//   * DeviceExec (sm_device.hip)  -> a real gfx950 work-group, `each` runs the
+//     lambda once for threadIdx.x and `sync` is s_barrier;
+//   * HostExec (tests/emul)       -> a sequential CPU emulation of one
+//     work-group, used by the "not gpu" tests to check indexing.
+// Pipeline for one pair-merge of two real [R x C] tensors a, b:
+//   F1  rows:    z = a + i b, C-point FFT per row, split by Hermitian symmetry
+//                into half-spectra A_row, B_row -> T1[R][Cb] (float4 per bin)
+//   F2  columns: R-point FFT per bin column of A and B -> planes [Cb][R]:
+//                Re Fa, Im Fa, Re Fb (normalised), + level-1 histogram
+//   SEL select:  exact k-th order statistic by 3-level radix histograms
+//   RED / BLEND: masked slerp sums, class blend -> Re R plane (+ cull histogram)
+//   I1  columns: inverse R-point FFT of (Re R culled, Im Fa) -> G[R][Cb]
+//   I2  rows:    two rows per transform (two-for-one), inverse C-point FFT,
+//                scale, NaN/Inf policy, add base, bf16 store
+#pragma once
+#include <cmath>
+#include <cstring>
+
+#include "fft_engine.hpp"
+
+namespace smhip {
+
+struct cf4 { float x, y, z, w; };
+struct u32x4 { uint32_t x, y, z, w; };
+
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+
+// value = (load(x) - (base ? load(base) : 0)) * prescale
+struct SigDesc {
+    const void* x;
+    const void* base;
+    int dtype;
+    float prescale;
+};
+
+SM_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+SM_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+SM_HD float bf16_to_f(uint32_t h) { return u2f(h << 16); }
+SM_HD float f16_to_f(uint32_t h) {
+    const uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    if (e == 0) {
+        if (m == 0) return u2f(s);
+        float v = (float)m * 5.9604644775390625e-08f;   // m * 2^-24
+        return (s ? -v : v);
+    }
+    if (e == 31) return u2f(s | 0x7f800000u | (m << 13));
+    return u2f(s | ((e + 112) << 23) | (m << 13));
+}
+// round-to-nearest-even; caller guarantees v is not NaN
+SM_HD uint16_t f_to_bf16(float v) {
+    uint32_t u = f2u(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+SM_HD bool is_nan(float v) { return v != v; }
+SM_HD bool is_inf(float v) { return (f2u(v) & 0x7fffffffu) == 0x7f800000u; }
+
+SM_HD float load_elem(const void* p, int dtype, size_t i) {
+    if (dtype == DT_F32) return ((const float*)p)[i];
+    const uint32_t h = ((const uint16_t*)p)[i];
+    return dtype == DT_BF16 ? bf16_to_f(h) : f16_to_f(h);
+}
+// 8 consecutive elements starting at i (i % 8 == 0, pointer 16-byte aligned)
+SM_HD void load_elem8(const void* p, int dtype, size_t i, float* out) {
+    if (dtype == DT_F32) {
+        const cf4 a = ((const cf4*)p)[i / 4], b = ((const cf4*)p)[i / 4 + 1];
+        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+        out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    } else {
+        const u32x4 v = ((const u32x4*)p)[i / 8];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (dtype == DT_BF16) {
+                out[2 * c] = u2f(w[c] << 16);
+                out[2 * c + 1] = u2f(w[c] & 0xffff0000u);
+            } else {
+                out[2 * c] = f16_to_f(w[c] & 0xffffu);
+                out[2 * c + 1] = f16_to_f(w[c] >> 16);
+            }
+        }
+    }
+}
+SM_HD void load_sig8(const SigDesc& s, size_t i, float* out) {
+    if (!s.x) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) out[c] = 0.f;
+        return;
+    }
+    load_elem8(s.x, s.dtype, i, out);
+    if (s.base) {
+        float b[8];
+        load_elem8(s.base, s.dtype, i, b);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) out[c] -= b[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[c] *= s.prescale;
+}
+SM_HD float load_sig1(const SigDesc& s, size_t i) {
+    if (!s.x) return 0.f;
+    float v = load_elem(s.x, s.dtype, i);
+    if (s.base) v -= load_elem(s.base, s.dtype, i);
+    return v * s.prescale;
+}
+
+// weight of a half-spectrum bin column: columns 0 and C/2 (C even) hold all of
+// their full-spectrum bins, every other column stands for itself and its
+// conjugate twin (multiplicities for the order statistics).
+// C < 0: the planes hold a full spectrum, every bin counts once.
+SM_HD int bin_weight(int k2, int C) { return (C < 0 || k2 == 0 || (2 * k2 == C)) ? 1 : 2; }
+
+struct FftState {
+    float xr[EREG];
+    float xi[EREG];
+    double red[4];
+};
+
+constexpr int LDS_SCRATCH_FLOATS = 64 * 4;   // reduction scratch at the start of LDS
+constexpr int HIST1_BINS = 2048;             // level 1: key >> 20
+constexpr int HIST_LO_BINS = 1024;           // levels 2, 3: 10 bits each
+
+// =====================================================================
+// F1: forward row pass
+// =====================================================================
+struct F1Params {
+    FftPlanDev plan;       // N = C
+    SigDesc a, b;
+    int R, C, Cb;
+    int pitch4;            // T1 row pitch in float4
+    int nb;                // rows (transforms) per work-group
+    int vec;               // 1: C % 8 == 0 and 16-byte aligned inputs
+    cf4* t1;
+    double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
+};
+
+template <class Ex>
+SM_HD void k_f1(Ex& ex, const F1Params& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    const int T = pl.T, C = p.C;
+    const int bid = ex.bid();
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int row = bid * p.nb + g;
+        const bool valid = row < p.R;
+        double sa = 0.0, sb = 0.0;
+        if (p.vec) {
+#pragma unroll
+            for (int q = 0; q < EMAX / 8; ++q) {
+                const int n0 = 8 * (t + q * T);
+                float va[8], vb[8];
+                if (valid && n0 < C) {
+                    const size_t off = (size_t)row * C + n0;
+                    load_sig8(p.a, off, va);
+                    load_sig8(p.b, off, vb);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { va[c] = 0.f; vb[c] = 0.f; }
+                }
+                float pa = 0.f, pb = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    s.xr[q * 8 + c] = va[c]; s.xi[q * 8 + c] = vb[c];
+                    pa += va[c] * va[c]; pb += vb[c] * vb[c];
+                }
+                sa += pa; sb += pb;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EMAX; ++q) {
+                const int n = t + q * T;
+                float va = 0.f, vb = 0.f;
+                if (valid && n < C) {
+                    const size_t off = (size_t)row * C + n;
+                    va = load_sig1(p.a, off);
+                    vb = load_sig1(p.b, off);
+                }
+                s.xr[q] = va; s.xi[q] = vb;
+                sa += (double)va * va; sb += (double)vb * vb;
+            }
+        }
+        s.red[0] = sa; s.red[1] = sb;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) {
+        p.partials[2 * (size_t)bid] = tot[0];
+        p.partials[2 * (size_t)bid + 1] = tot[1];
+    });
+
+    wg_fft(ex, st, pl, lds,
+        [&](int tid, FftState& s, int comp) {          // natural scatter
+            const int g = tid / T, t = tid % T;
+            float* l = lds + g * pl.lds_floats;
+            const float* x = comp ? s.xi : s.xr;
+            if (p.vec) {
+#pragma unroll
+                for (int q = 0; q < EMAX / 8; ++q) {
+                    const int n0 = 8 * (t + q * T);
+                    if (n0 < C) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) l[lpad(n0 + c)] = x[q * 8 + c];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EMAX; ++q) {
+                    const int n = t + q * T;
+                    if (n < C) l[lpad(n)] = x[q];
+                }
+            }
+        },
+        [&](int tid, FftState& s, int comp) {          // final gather: pairs (k, C-k)
+            const int g = tid / T, t = tid % T;
+            const float* l = lds + g * pl.lds_floats;
+            float* o = comp ? s.xi : s.xr;
+#pragma unroll
+            for (int u = 0; u < EMAX / 2 + 1; ++u) {
+                const int k = t + u * T;
+                if (k < p.Cb) {
+                    const int k2 = (k == 0) ? 0 : C - k;
+                    const float v1 = l[lpad(k)], v2 = l[lpad(k2)];
+                    if (comp == 0) { o[2 * u] = 0.5f * (v1 + v2); o[2 * u + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
+                    else           { o[2 * u] = 0.5f * (v1 - v2); o[2 * u + 1] = 0.5f * (v1 + v2); }   // A.im, B.re
+                }
+            }
+        });
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int row = bid * p.nb + g;
+        if (row >= p.R) return;
+        cf4* dst = p.t1 + (size_t)row * p.pitch4;
+#pragma unroll
+        for (int u = 0; u < EMAX / 2 + 1; ++u) {
+            const int k = t + u * T;
+            if (k < p.Cb) {
+                cf4 v;
+                v.x = s.xr[2 * u]; v.y = s.xi[2 * u]; v.z = s.xi[2 * u + 1]; v.w = s.xr[2 * u + 1];
+                dst[k] = v;
+            }
+        }
+    });
+}
+
+// =====================================================================
+// F2: forward column pass (one half-spectrum bin column of A and of B)
+// =====================================================================
+struct F2Params {
+    FftPlanDev plan;       // N = R
+    const cf4* t1;
+    int pitch4;
+    int R, C, Cb;
+    int nsig;              // 2: A and B in one work-group; 1: one signal per work-group
+    int swap;              // 1: slot B plays role "a" (the larger-norm input)
+    float scale[2];        // per slot: 1/norm (or the arithmetic branch's scale)
+    float* reA; float* imA; float* reB;     // planes [Cb][R]; role b writes only reB
+    unsigned long long* hist;               // level-1 histogram (HIST1_BINS) or null
+};
+
+template <class Ex>
+SM_HD void k_f2(Ex& ex, const F2Params& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    const int T = pl.T, R = p.R;
+    const int ng = p.nsig;
+    const int bid = ex.bid();
+    const int k2 = (ng == 2) ? bid : bid / 2;
+    const int slot0 = (ng == 2) ? 0 : bid % 2;
+    uint32_t* lhist = (uint32_t*)(lds + ng * pl.lds_floats);
+
+    ex.each(st, [&](int tid, FftState& s) {
+        if (ng == 2) {
+#pragma unroll
+            for (int q = 0; q < EMAX / 2; ++q) {
+                const int n = tid + q * 2 * T;
+                cf4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < R) v = p.t1[(size_t)n * p.pitch4 + k2];
+                s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EMAX; ++q) {
+                const int n = tid + q * T;
+                float re = 0.f, im = 0.f;
+                if (n < R) {
+                    const cf2* src = (const cf2*)(p.t1 + (size_t)n * p.pitch4 + k2) + slot0;
+                    re = src->x; im = src->y;
+                }
+                s.xr[q] = re; s.xi[q] = im;
+            }
+        }
+        if (p.hist) for (int b = tid; b < HIST1_BINS; b += ng * T) lhist[b] = 0;
+    });
+
+    wg_fft(ex, st, pl, lds,
+        [&](int tid, FftState& s, int comp) {
+            const float* x = comp ? s.xi : s.xr;
+            if (ng == 2) {
+#pragma unroll
+                for (int q = 0; q < EMAX / 2; ++q) {
+                    const int n = tid + q * 2 * T;
+                    if (n < R) { lds[lpad(n)] = x[2 * q]; lds[pl.lds_floats + lpad(n)] = x[2 * q + 1]; }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EMAX; ++q) {
+                    const int n = tid + q * T;
+                    if (n < R) lds[lpad(n)] = x[q];
+                }
+            }
+        },
+        [&](int tid, FftState& s, int comp) {
+            const int g = tid / T, t = tid % T;
+            const float* l = lds + g * pl.lds_floats;
+            float* o = comp ? s.xi : s.xr;
+#pragma unroll
+            for (int u = 0; u < EMAX / 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k1 = 4 * (t + u * T) + c;
+                    if (k1 < R) o[4 * u + c] = l[lpad(k1)];
+                }
+            }
+        });
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int slot = slot0 + g;
+        const bool role_a = (slot ^ p.swap) == 0;
+        const float sc = p.scale[slot];
+        const uint32_t w = (uint32_t)bin_weight(k2, p.C);
+        float* dre = (role_a ? p.reA : p.reB) + (size_t)k2 * R;
+        float* dim = p.imA + (size_t)k2 * R;
+#pragma unroll
+        for (int u = 0; u < EMAX / 4; ++u) {
+            const int k0 = 4 * (t + u * T);
+            if (k0 + 3 < R && (R & 3) == 0) {
+                cf4 vr = {s.xr[4 * u] * sc, s.xr[4 * u + 1] * sc, s.xr[4 * u + 2] * sc, s.xr[4 * u + 3] * sc};
+                *(cf4*)(dre + k0) = vr;
+                if (role_a) {
+                    cf4 vi = {s.xi[4 * u] * sc, s.xi[4 * u + 1] * sc, s.xi[4 * u + 2] * sc, s.xi[4 * u + 3] * sc};
+                    *(cf4*)(dim + k0) = vi;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (k0 + c < R) {
+                        dre[k0 + c] = s.xr[4 * u + c] * sc;
+                        if (role_a) dim[k0 + c] = s.xi[4 * u + c] * sc;
+                    }
+                }
+            }
+            if (p.hist) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (k0 + c < R) {
+                        const uint32_t key = f2u(s.xr[4 * u + c] * sc) & 0x7fffffffu;
+                        ex.lds_atomic_add(&lhist[key >> 20], w);
+                    }
+                }
+            }
+        }
+    });
+    if (p.hist) {
+        ex.sync();
+        ex.each(st, [&](int tid, FftState&) {
+            for (int b = tid; b < HIST1_BINS; b += ng * T) {
+                const uint32_t v = lhist[b];
+                if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+            }
+        });
+    }
+}
+
+// =====================================================================
+// I1: inverse column pass
+// =====================================================================
+struct I1Params {
+    FftPlanDev plan;       // N = R
+    const float* reR;      // Re R plane [Cb][R] (cull applied on read)
+    const float* imA;      // Im plane
+    const float* cull_thr; // device scalar or null: |re| < *cull_thr -> 0
+    int R, Cb;
+    int s;                 // bin columns per work-group
+    cf2* G;                // [R][pitchG]
+    int pitchG;
+};
+
+template <int S, class Ex>
+SM_HD void k_i1(Ex& ex, const I1Params& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    const int T = pl.T, R = p.R;
+    const int bid = ex.bid();
+    const float thr = p.cull_thr ? *p.cull_thr : 0.f;
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int k2 = bid * S + g;
+        const bool valid = k2 < p.Cb;
+        const float* sre = p.reR + (size_t)k2 * R;
+        const float* sim = p.imA + (size_t)k2 * R;
+#pragma unroll
+        for (int u = 0; u < EMAX / 4; ++u) {
+            const int k0 = 4 * (t + u * T);
+            float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+                if (k0 + 3 < R && (R & 3) == 0) {
+                    const cf4 a = *(const cf4*)(sre + k0), b = *(const cf4*)(sim + k0);
+                    re[0] = a.x; re[1] = a.y; re[2] = a.z; re[3] = a.w;
+                    im[0] = b.x; im[1] = b.y; im[2] = b.z; im[3] = b.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (k0 + c < R) { re[c] = sre[k0 + c]; im[c] = sim[k0 + c]; }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (fabsf(re[c]) < thr) re[c] = 0.f;
+                // inverse via the swap trick: ifft(x) = swap(fft(swap(x)))
+                s.xr[4 * u + c] = im[c];
+                s.xi[4 * u + c] = re[c];
+            }
+        }
+    });
+
+    wg_fft(ex, st, pl, lds,
+        [&](int tid, FftState& s, int comp) {
+            const int g = tid / T, t = tid % T;
+            float* l = lds + g * pl.lds_floats;
+            const float* x = comp ? s.xi : s.xr;
+#pragma unroll
+            for (int u = 0; u < EMAX / 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k1 = 4 * (t + u * T) + c;
+                    if (k1 < R) l[lpad(k1)] = x[4 * u + c];
+                }
+            }
+        },
+        [&](int tid, FftState& s, int comp) {
+            float* o = comp ? s.xi : s.xr;
+            // thread handles rows r = tid + q*(S*T); needs every group's value
+#pragma unroll
+            for (int q = 0; q < EMAX / S; ++q) {
+                const int r = tid + q * S * T;
+                if (r < R) {
+#pragma unroll
+                    for (int g = 0; g < S; ++g) o[q * S + g] = lds[g * pl.lds_floats + lpad(r)];
+                }
+            }
+        });
+
+    ex.each(st, [&](int tid, FftState& s) {
+#pragma unroll
+        for (int q = 0; q < EMAX / S; ++q) {
+            const int r = tid + q * S * T;
+            if (r < R) {
+                cf2* dst = p.G + (size_t)r * p.pitchG + (size_t)bid * S;
+                if constexpr (S == 2) {
+                    // swap trick: true (re, im) = (xi, xr); pitchG is even, so the
+                    // pad column absorbs the second bin of the last work-group
+                    cf4 v = {s.xi[2 * q], s.xr[2 * q], s.xi[2 * q + 1], s.xr[2 * q + 1]};
+                    *(cf4*)dst = v;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < S; ++g) {
+                        if (bid * S + g < p.pitchG) {
+                            cf2 v = {s.xi[q * S + g], s.xr[q * S + g]};
+                            dst[g] = v;
+                        }
+                    }
+                }
+            }
+        }
+    });
+}
+
+// =====================================================================
+// I2: inverse row pass, two rows per transform
+// =====================================================================
+enum { OUT_BF16 = 0, OUT_F32 = 1 };
+struct I2Params {
+    FftPlanDev plan;       // N = C
+    const cf2* G;
+    int pitchG;
+    int R, C, Cb;
+    int nb;                // row pairs per work-group
+    int vec;               // C % 8 == 0 (and aligned out/base)
+    float inv_n;           // 1/(R*C): the inverse transform's normalisation
+    float post;            // target_norm (1 for the arithmetic branch / raw merges)
+    int ifft_policy;       // 1: NaN -> 0 (counted) and Inf flagged right after the inverse transform
+    const void* base; int base_dtype;   // add-back tensor or null
+    void* out; int out_mode;
+    uint32_t* flags;       // [0] NaNs zeroed after ifft, [1] Inf after ifft, [2] NaNs zeroed after add-back, [3] Inf after add-back
+};
+
+SM_HD void i2_finish(const I2Params& p, float v, size_t off, uint32_t& nan1, uint32_t& inf1, uint32_t& nan2, uint32_t& inf2, float& outv) {
+    v *= p.inv_n;
+    if (p.ifft_policy) {
+        if (is_nan(v)) { v = 0.f; nan1++; }
+        if (is_inf(v)) inf1 = 1;
+    }
+    v *= p.post;
+    if (p.base) {
+        v += load_elem(p.base, p.base_dtype, off);
+        if (is_nan(v)) { v = 0.f; nan2++; }
+        if (is_inf(v)) inf2 = 1;
+    }
+    outv = v;
+}
+
+template <class Ex>
+SM_HD void k_i2(Ex& ex, const I2Params& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    const int T = pl.T, C = p.C;
+    const int bid = ex.bid();
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int r0 = 2 * (bid * p.nb + g), r1 = r0 + 1;
+        const bool v0 = r0 < p.R, v1 = r1 < p.R;
+#pragma unroll
+        for (int u = 0; u < EMAX / 2 + 1; ++u) {
+            const int k = t + u * T;
+            if (k < p.Cb) {
+                cf2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f};
+                if (v0) g0 = p.G[(size_t)r0 * p.pitchG + k];
+                if (v1) g1 = p.G[(size_t)r1 * p.pitchG + k];
+                if (k == 0 || 2 * k == C) { g0.y = 0.f; g1.y = 0.f; }   // c2r: DC / Nyquist are real
+                // Y[k] = G0[k] + i G1[k];  Y[C-k] = conj(G0[k]) + i conj(G1[k])
+                const float ykr = g0.x - g1.y, yki = g0.y + g1.x;
+                const float ymr = g0.x + g1.y, ymi = g1.x - g0.y;
+                // swap trick on input: feed (im, re)
+                s.xr[2 * u] = yki; s.xi[2 * u] = ykr;
+                s.xr[2 * u + 1] = ymi; s.xi[2 * u + 1] = ymr;
+            }
+        }
+    });
+
+    wg_fft(ex, st, pl, lds,
+        [&](int tid, FftState& s, int comp) {
+            const int g = tid / T, t = tid % T;
+            float* l = lds + g * pl.lds_floats;
+            const float* x = comp ? s.xi : s.xr;
+#pragma unroll
+            for (int u = 0; u < EMAX / 2 + 1; ++u) {
+                const int k = t + u * T;
+                if (k < p.Cb) {
+                    l[lpad(k)] = x[2 * u];
+                    if (k != 0 && 2 * k != C) l[lpad(C - k)] = x[2 * u + 1];
+                }
+            }
+        },
+        [&](int tid, FftState& s, int comp) {
+            const int g = tid / T, t = tid % T;
+            const float* l = lds + g * pl.lds_floats;
+            float* o = comp ? s.xi : s.xr;
+            if (p.vec) {
+#pragma unroll
+                for (int q = 0; q < EMAX / 8; ++q) {
+                    const int n0 = 8 * (t + q * T);
+                    if (n0 < C) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o[q * 8 + c] = l[lpad(n0 + c)];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EMAX; ++q) {
+                    const int n = t + q * T;
+                    if (n < C) o[q] = l[lpad(n)];
+                }
+            }
+        });
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int r0 = 2 * (bid * p.nb + g);
+        uint32_t nan1 = 0, inf1 = 0, nan2 = 0, inf2 = 0;
+        // after the swap trick the true (re, im) = (xi, xr): row r0 = re, row r0+1 = im
+        for (int h = 0; h < 2; ++h) {
+            const int row = r0 + h;
+            if (row >= p.R) continue;
+            const float* x = h ? s.xr : s.xi;
+            if (p.vec) {
+#pragma unroll
+                for (int q = 0; q < EMAX / 8; ++q) {
+                    const int n0 = 8 * (t + q * T);
+                    if (n0 < C) {
+                        const size_t off = (size_t)row * C + n0;
+                        float o[8];
+                        float bv[8];
+                        if (p.base) load_elem8(p.base, p.base_dtype, off, bv);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float v = x[q * 8 + c] * p.inv_n;
+                            if (p.ifft_policy) {
+                                if (is_nan(v)) { v = 0.f; nan1++; }
+                                if (is_inf(v)) inf1 = 1;
+                            }
+                            v *= p.post;
+                            if (p.base) {
+                                v += bv[c];
+                                if (is_nan(v)) { v = 0.f; nan2++; }
+                                if (is_inf(v)) inf2 = 1;
+                            }
+                            o[c] = v;
+                        }
+                        if (p.out_mode == OUT_BF16) {
+                            u32x4 w;
+                            w.x = (uint32_t)f_to_bf16(o[0]) | ((uint32_t)f_to_bf16(o[1]) << 16);
+                            w.y = (uint32_t)f_to_bf16(o[2]) | ((uint32_t)f_to_bf16(o[3]) << 16);
+                            w.z = (uint32_t)f_to_bf16(o[4]) | ((uint32_t)f_to_bf16(o[5]) << 16);
+                            w.w = (uint32_t)f_to_bf16(o[6]) | ((uint32_t)f_to_bf16(o[7]) << 16);
+                            ((u32x4*)p.out)[off / 8] = w;
+                        } else {
+                            cf4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
+                            ((cf4*)p.out)[off / 4] = w0;
+                            ((cf4*)p.out)[off / 4 + 1] = w1;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EMAX; ++q) {
+                    const int n = t + q * T;
+                    if (n < C) {
+                        const size_t off = (size_t)row * C + n;
+                        float v;
+                        i2_finish(p, x[q], off, nan1, inf1, nan2, inf2, v);
+                        if (p.out_mode == OUT_BF16) ((uint16_t*)p.out)[off] = f_to_bf16(v);
+                        else ((float*)p.out)[off] = v;
+                    }
+                }
+            }
+        }
+        if (nan1) ex.global_atomic_add_u32(&p.flags[0], nan1);
+        if (inf1) ex.global_atomic_or_u32(&p.flags[1], 1u);
+        if (nan2) ex.global_atomic_add_u32(&p.flags[2], nan2);
+        if (inf2) ex.global_atomic_or_u32(&p.flags[3], 1u);
+    });
+}
+
+// =====================================================================
+// streaming kernels over the half-spectrum planes [Cb][R]
+// =====================================================================
+struct EmptyState { double red[8]; };
+
+// selection state (device memory): exact k-th smallest key by radix levels
+struct SelState {
+    unsigned long long rank;    // in: 0-based rank wanted; updated to rank within the prefix
+    uint32_t prefix;            // key bits decided so far
+    uint32_t level;             // levels done
+    float value;                // final: the k-th smallest |x|
+    uint32_t pad;
+};
+
+struct HistParams {
+    const float* X; const float* Y;     // Y may be null
+    int R, C, Cb;
+    int vec4;                           // R % 4 == 0: float4 loads, one weight per quad
+    int level;                          // 1, 2 or 3
+    const SelState* sel;
+    unsigned long long* hist;
+    int chunks;                         // quads per thread
+};
+
+// load up to 4 consecutive plane values starting at element i0
+SM_HD int load_quad(const float* src, size_t i0, size_t total, int vec4, float* out) {
+    if (vec4) {
+        const cf4 v = *(const cf4*)(src + i0);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        return 4;
+    }
+    int n = 0;
+    for (int e = 0; e < 4; ++e) {
+        if (i0 + e < total) { out[e] = src[i0 + e]; n = e + 1; } else out[e] = 0.f;
+    }
+    return n;
+}
+
+template <class Ex>
+SM_HD void k_hist(Ex& ex, const HistParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    const int nbins = p.level == 1 ? HIST1_BINS : HIST_LO_BINS;
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    const uint32_t prefix = p.sel->prefix;
+    ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < nbins; b += nt) lh[b] = 0; });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t qi = start + (size_t)c * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            for (int which = 0; which < 2; ++which) {
+                const float* src = which ? p.Y : p.X;
+                if (!src) continue;
+                float v[4];
+                const int n = load_quad(src, i0, total, p.vec4, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < n) {
+                        const uint32_t w = (uint32_t)bin_weight((int)((i0 + e) / p.R), p.C);
+                        const uint32_t key = f2u(v[e]) & 0x7fffffffu;
+                        if (p.level == 1) ex.lds_atomic_add(&lh[key >> 20], w);
+                        else if (p.level == 2) { if ((key >> 20) == prefix) ex.lds_atomic_add(&lh[(key >> 10) & 1023u], w); }
+                        else { if ((key >> 10) == prefix) ex.lds_atomic_add(&lh[key & 1023u], w); }
+                    }
+                }
+            }
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int b = tid; b < nbins; b += nt) {
+            const uint32_t v = lh[b];
+            if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+        }
+    });
+}
+
+struct ScanParams {
+    unsigned long long* hist;   // consumed and zeroed
+    SelState* sel;
+    int nbins;                  // HIST1_BINS or HIST_LO_BINS
+    int shift;                  // bits this level contributes (11 or 10)
+    int final_level;            // 1: write sel->value
+    float* value_out;           // optional extra copy of the value
+    int init;                   // 1: first level, start from rank_init / empty prefix
+    unsigned long long rank_init;
+};
+
+// single work-group of 256 threads
+template <class Ex>
+SM_HD void k_scan(Ex& ex, const ScanParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    unsigned long long* part = (unsigned long long*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    const int per = (p.nbins + nt - 1) / nt;
+    ex.each(st, [&](int tid, EmptyState&) {
+        unsigned long long s = 0;
+        for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) s += p.hist[b];
+        part[tid] = s;
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        unsigned long long excl = 0, total = 0;
+        for (int q = 0; q < nt; ++q) { if (q < tid) excl += part[q]; total += part[q]; }
+        unsigned long long rank = p.init ? p.rank_init : p.sel->rank;
+        const uint32_t prefix0 = p.init ? 0u : p.sel->prefix;
+        const uint32_t level0 = p.init ? 0u : p.sel->level;
+        if (total == 0) { if (tid == 0) { p.sel->value = 0.f; if (p.value_out) *p.value_out = 0.f; } return; }
+        if (rank >= total) rank = total - 1;
+        if (rank >= excl && rank < excl + part[tid]) {
+            unsigned long long cum = excl;
+            for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) {
+                const unsigned long long h = p.hist[b];
+                if (rank < cum + h) {
+                    const uint32_t np = (prefix0 << p.shift) | (uint32_t)b;
+                    p.sel->prefix = np;
+                    p.sel->rank = rank - cum;
+                    p.sel->level = level0 + 1;
+                    if (p.final_level) {
+                        p.sel->value = u2f(np);
+                        if (p.value_out) *p.value_out = u2f(np);
+                    }
+                    break;
+                }
+                cum += h;
+            }
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) p.hist[b] = 0;
+    });
+}
+
+// blend constants (device memory), written by k_slerp_consts
+struct BlendConsts {
+    float thr;        // cutoff threshold (0 when cutoff_pct == 0)
+    float dot;        // clamped cosine between the slerp-class vectors
+    float cos_t, sin_t;
+    float inv_rel;    // 1 / max(||v1 - dot v0||, 1e-12)
+    float pad[3];
+    double s00, s01, s11;
+    unsigned long long n_slerp;
+};
+
+struct ReduceParams {
+    const float* reA; const float* reB;
+    int R, C, Cb;
+    int vec4;
+    const float* thr;           // device scalar (cutoff threshold) or null (-> 0)
+    double* partials;           // [grid][4]: s00, s01, s11, count
+    int chunks;
+};
+
+SM_HD int sgn(float v) { return (v > 0.f) - (v < 0.f); }
+// torch.sign(NaN) = NaN and NaN == NaN is False: NaNs never "agree"
+SM_HD bool same_sign(float a, float b) { return !is_nan(a) && !is_nan(b) && sgn(a) == sgn(b); }
+
+template <class Ex>
+SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    const float thr = p.thr ? *p.thr : 0.f;
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t qi = start + (size_t)c * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            float a[4], b[4];
+            const int n = load_quad(p.reA, i0, total, p.vec4, a);
+            load_quad(p.reB, i0, total, p.vec4, b);
+            float q00 = 0.f, q01 = 0.f, q11 = 0.f, qc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < n && same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr)) {
+                    const float w = (float)bin_weight((int)((i0 + e) / p.R), p.C);
+                    q00 += w * a[e] * a[e]; q01 += w * a[e] * b[e]; q11 += w * b[e] * b[e]; qc += w;
+                }
+            }
+            s00 += q00; s01 += q01; s11 += q11; cnt += qc;
+        }
+        s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
+    });
+}
+
+struct SlerpConstParams {
+    const double* partials; int nparts;
+    const float* thr;           // device scalar or null (-> 0)
+    float t;
+    BlendConsts* out;
+};
+
+// single thread: sum the partials in a fixed order and derive the constants
+// (reference functions.py:36-43 on the gathered slerp-class vectors)
+template <class Ex>
+SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid != 0) return;
+        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
+        for (int i = 0; i < p.nparts; ++i) {
+            s00 += p.partials[4 * i]; s01 += p.partials[4 * i + 1];
+            s11 += p.partials[4 * i + 2]; cnt += p.partials[4 * i + 3];
+        }
+        BlendConsts c;
+        c.thr = p.thr ? *p.thr : 0.f;
+        c.s00 = s00; c.s01 = s01; c.s11 = s11; c.n_slerp = (unsigned long long)cnt;
+        double dot = s01 / (sqrt(s00) * sqrt(s11));
+        if (dot > 1.0) dot = 1.0;
+        if (dot < -1.0) dot = -1.0;
+        const float dotf = (float)dot;
+        const float theta = acosf(dotf) * p.t;
+        double rel2 = s11 - 2.0 * (double)dotf * s01 + (double)dotf * (double)dotf * s00;
+        if (rel2 < 0) rel2 = 0;
+        double reln = sqrt(rel2);
+        if (reln < 1e-12) reln = 1e-12;
+        c.dot = dotf; c.cos_t = cosf(theta); c.sin_t = sinf(theta); c.inv_rel = (float)(1.0 / reln);
+        c.pad[0] = c.pad[1] = c.pad[2] = 0.f;
+        *p.out = c;
+    });
+}
+
+enum { BLEND_SLERP = 0, BLEND_ARITH = 1 };
+struct BlendParams {
+    const float* reA; const float* reB;
+    float* reR;
+    int R, C, Cb;
+    int vec4;
+    int mode;
+    int agreement;              // arithmetic branch: sign agreement on/off
+    float t;                    // arithmetic: R = ra + t*rb
+    float t_sum;
+    const BlendConsts* consts;  // slerp mode
+    unsigned long long* hist;   // level-1 histogram of |Re R| for the cull, or null
+    int chunks;
+};
+
+SM_HD float blend_one(const BlendParams& p, const BlendConsts& c, float a, float b) {
+    if (p.mode == BLEND_SLERP) {
+        if (same_sign(a, b)) {
+            if (fabsf(b) < c.thr) return a + p.t_sum * b;
+            return a * c.cos_t + ((b - a * c.dot) * c.inv_rel) * c.sin_t;
+        }
+        return (fabsf(a) > fabsf(b)) ? a : b;
+    }
+    const bool agree = p.agreement ? same_sign(a, b) : true;
+    return agree ? (a + p.t * b) : b;                 // quirk Q3: disagreeing bins take b
+}
+
+template <class Ex>
+SM_HD void k_blend(Ex& ex, const BlendParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    BlendConsts c;
+    memset(&c, 0, sizeof(c));
+    if (p.mode == BLEND_SLERP) c = *p.consts;
+    if (p.hist) {
+        ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
+        ex.sync();
+    }
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t qi = start + (size_t)q * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            float a[4], b[4], r[4];
+            const int n = load_quad(p.reA, i0, total, p.vec4, a);
+            load_quad(p.reB, i0, total, p.vec4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = blend_one(p, c, a[e], b[e]);
+            if (p.vec4) {
+                cf4 v = {r[0], r[1], r[2], r[3]};
+                *(cf4*)(p.reR + i0) = v;
+            } else {
+                for (int e = 0; e < n; ++e) p.reR[i0 + e] = r[e];
+            }
+            if (p.hist) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < n) {
+                        const uint32_t key = f2u(r[e]) & 0x7fffffffu;
+                        ex.lds_atomic_add(&lh[key >> 20], (uint32_t)bin_weight((int)((i0 + e) / p.R), p.C));
+                    }
+                }
+            }
+        }
+    });
+    if (p.hist) {
+        ex.sync();
+        ex.each(st, [&](int tid, EmptyState&) {
+            for (int b = tid; b < HIST1_BINS; b += nt) {
+                const uint32_t v = lh[b];
+                if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+            }
+        });
+    }
+}
+
+// =====================================================================
+// elementwise spatial kernels (deltas, norms, add branch, K=1 finish)
+// =====================================================================
+struct CombineParams {
+    SigDesc a, b;               // b.x may be null
+    float ca, cb;               // out = ca*a + cb*b
+    size_t n;
+    int vec8;                   // n % 8 == 0 and every pointer 16-byte aligned
+    float* out_f32;             // or null (norms only)
+    // optional finish: add base, NaN/Inf policy, bf16 / f32 store
+    const void* base; int base_dtype;
+    void* out_final; int out_mode;
+    uint32_t* flags;
+    double* partials;           // [grid][2] sum a^2, sum b^2 (of the un-weighted signals) or null
+    int chunks;                 // octets per thread
+};
+
+template <class Ex>
+SM_HD void k_combine(Ex& ex, const CombineParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t noct = (p.n + 7) / 8;
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double sa = 0, sb = 0;
+        uint32_t nan2 = 0, inf2 = 0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t oi = start + (size_t)q * nt + tid;
+            if (oi >= noct) break;
+            const size_t i0 = 8 * oi;
+            float a[8], b[8], bs[8], o[8];
+            int cnt = 8;
+            if (p.vec8) {
+                load_sig8(p.a, i0, a);
+                load_sig8(p.b, i0, b);
+                if (p.out_final && p.base) load_elem8(p.base, p.base_dtype, i0, bs);
+            } else {
+                cnt = (int)((p.n - i0) < 8 ? (p.n - i0) : 8);
+                for (int e = 0; e < 8; ++e) {
+                    a[e] = b[e] = bs[e] = 0.f;
+                    if (e < cnt) {
+                        a[e] = load_sig1(p.a, i0 + e); b[e] = load_sig1(p.b, i0 + e);
+                        if (p.out_final && p.base) bs[e] = load_elem(p.base, p.base_dtype, i0 + e);
+                    }
+                }
+            }
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pa += a[e] * a[e]; pb += b[e] * b[e];
+                float v = p.ca * a[e] + (p.b.x ? p.cb * b[e] : 0.f);
+                o[e] = v;
+            }
+            sa += pa; sb += pb;
+            if (p.out_f32) {
+                if (p.vec8) {
+                    cf4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
+                    ((cf4*)p.out_f32)[i0 / 4] = w0; ((cf4*)p.out_f32)[i0 / 4 + 1] = w1;
+                } else {
+                    for (int e = 0; e < cnt; ++e) p.out_f32[i0 + e] = o[e];
+                }
+            }
+            if (p.out_final) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = o[e];
+                    if (p.base) v += bs[e];
+                    if (e < cnt) {
+                        if (is_nan(v)) { v = 0.f; nan2++; }
+                        if (is_inf(v)) inf2 = 1;
+                    }
+                    o[e] = v;
+                }
+                if (p.vec8 && p.out_mode == OUT_BF16) {
+                    u32x4 w;
+                    w.x = (uint32_t)f_to_bf16(o[0]) | ((uint32_t)f_to_bf16(o[1]) << 16);
+                    w.y = (uint32_t)f_to_bf16(o[2]) | ((uint32_t)f_to_bf16(o[3]) << 16);
+                    w.z = (uint32_t)f_to_bf16(o[4]) | ((uint32_t)f_to_bf16(o[5]) << 16);
+                    w.w = (uint32_t)f_to_bf16(o[6]) | ((uint32_t)f_to_bf16(o[7]) << 16);
+                    ((u32x4*)p.out_final)[oi] = w;
+                } else {
+                    for (int e = 0; e < cnt; ++e) {
+                        if (p.out_mode == OUT_BF16) ((uint16_t*)p.out_final)[i0 + e] = f_to_bf16(o[e]);
+                        else ((float*)p.out_final)[i0 + e] = o[e];
+                    }
+                }
+            }
+        }
+        s.red[0] = sa; s.red[1] = sb;
+        if (nan2) ex.global_atomic_add_u32(&p.flags[2], nan2);
+        if (inf2) ex.global_atomic_or_u32(&p.flags[3], 1u);
+    });
+    if (p.partials) {
+        ex.template block_sum<2>(st, [&](const double* tot) {
+            p.partials[2 * (size_t)ex.bid()] = tot[0];
+            p.partials[2 * (size_t)ex.bid() + 1] = tot[1];
+        });
+    }
+}
+
+// expand half-spectrum planes to the full complex spectrum (test / API helper:
+// the reference's fft_transform returns all R x C bins)
+struct ExpandParams {
+    const float* re; const float* im;   // planes [Cb][R]
+    int R, C, Cb;
+    cf2* full;                          // [R][C]
+    int chunks;
+};
+template <class Ex>
+SM_HD void k_expand(Ex& ex, const ExpandParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.R * p.C;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t i = start + (size_t)q * nt + tid;
+            if (i >= total) break;
+            const int r = (int)(i / p.C), k = (int)(i % p.C);
+            cf2 v;
+            if (k < p.Cb) {
+                v.x = p.re[(size_t)k * p.R + r]; v.y = p.im[(size_t)k * p.R + r];
+            } else {
+                const int kk = p.C - k, rr = (p.R - r) % p.R;
+                v.x = p.re[(size_t)kk * p.R + rr]; v.y = -p.im[(size_t)kk * p.R + rr];
+            }
+            p.full[i] = v;
+        }
+    });
+}
+
+// gather a full complex spectrum [R][C] (interleaved) into half-spectrum planes
+// [Cb][R].  sym = 1 first projects onto the Hermitian part, which is what taking
+// `.real` of the inverse transform does (reference functions.py:71-73).
+struct PackParams {
+    const cf2* full; int R, C, Cb;
+    float* re; float* im;
+    int sym;
+    int chunks;
+};
+template <class Ex>
+SM_HD void k_pack(Ex& ex, const PackParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t i = start + (size_t)q * nt + tid;
+            if (i >= total) break;
+            const int k = (int)(i / p.R), r = (int)(i % p.R);
+            cf2 v = p.full[(size_t)r * p.C + k];
+            if (p.sym) {
+                const int rr = (p.R - r) % p.R, kk = (p.C - k) % p.C;
+                const cf2 m = p.full[(size_t)rr * p.C + kk];
+                v.x = 0.5f * (v.x + m.x); v.y = 0.5f * (v.y - m.y);
+            }
+            p.re[i] = v.x; p.im[i] = v.y;
+        }
+    });
+}
+
+// interleaved complex <-> two planes in the same (row-major) order; cull in place
+struct SplitParams { const cf2* full; float* re; float* im; size_t n; int chunks; };
+template <class Ex>
+SM_HD void k_split(Ex& ex, const SplitParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t i = start + (size_t)q * nt + tid;
+            if (i >= p.n) break;
+            const cf2 v = p.full[i];
+            p.re[i] = v.x; p.im[i] = v.y;
+        }
+    });
+}
+struct JoinParams { const float* re; const float* im; cf2* full; size_t n; int chunks; };
+template <class Ex>
+SM_HD void k_join(Ex& ex, const JoinParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t i = start + (size_t)q * nt + tid;
+            if (i >= p.n) break;
+            cf2 v = {p.re[i], p.im[i]};
+            p.full[i] = v;
+        }
+    });
+}
+struct CullParams { float* x; size_t n; const float* thr; int chunks; };
+template <class Ex>
+SM_HD void k_cull(Ex& ex, const CullParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const float thr = *p.thr;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t i = start + (size_t)q * nt + tid;
+            if (i >= p.n) break;
+            if (fabsf(p.x[i]) < thr) p.x[i] = 0.f;
+        }
+    });
+}
+
+}  // namespace smhip

@@ -1,0 +1,832 @@
+// sm_pipeline.hpp - host-side orchestration of the spectral-merge pipeline,
+// templated on a Backend (HipBackend in smhip_hip.hip; HostBackend in the CPU
+// emulator under tests/emul).  Holds the FFT planner, the workspace, the pair
+// merge sequence and the per-layer tournament of FourierMerge._merge_layer
+// (reference shard/merge/fast_fourier.py:132-276).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/shardmerge_hip.h"
+#include "sm_kernels.hpp"
+
+namespace smhip {
+
+// ---- kernel tags -------------------------------------------------------------
+#define SM_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                      \
+    struct Tag {                                                                     \
+        using Params = ParamsT;                                                      \
+        static const char* name() { return NAME; }                                   \
+        template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
+    };
+SM_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1(ex, p))
+SM_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", k_f2(ex, p))
+SM_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv_s1", k_i1<1>(ex, p))
+SM_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv_s2", k_i1<2>(ex, p))
+SM_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2(ex, p))
+SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
+SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
+SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
+SM_KERNEL_TAG(KSlerpConsts, SlerpConstParams, "slerp_consts", k_slerp_consts(ex, p))
+SM_KERNEL_TAG(KBlend, BlendParams, "blend", k_blend(ex, p))
+SM_KERNEL_TAG(KCombine, CombineParams, "combine", k_combine(ex, p))
+SM_KERNEL_TAG(KExpand, ExpandParams, "expand_full", k_expand(ex, p))
+SM_KERNEL_TAG(KPack, PackParams, "pack_planes", k_pack(ex, p))
+SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
+SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
+SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
+
+// ---- FFT planner ---------------------------------------------------------------
+struct HostPlan {
+    FftPlanDev dev;
+    bool ok = false;
+};
+
+inline bool plan_radices(int N, int T, std::vector<int>& out) {
+    out.clear();
+    if (N == 1) { out.push_back(1); return true; }
+    int rest = N, a = 0;
+    while (rest % 2 == 0) { rest /= 2; ++a; }
+    std::vector<int> odd;
+    for (int p : {3, 5, 7, 11, 13})
+        while (rest % p == 0) { rest /= p; odd.push_back(p); }
+    if (rest != 1) return false;
+    if (a > 0) {
+        const int np = (a + 4) / 5;
+        const int base = a / np, extra = a % np;
+        for (int i = 0; i < np; ++i) out.push_back(1 << (base + (i < extra ? 1 : 0)));
+    }
+    for (int p : odd) out.push_back(p);
+    if ((int)out.size() > MAX_PASSES) return false;
+    for (int r : out) {
+        const int nb = N / r;
+        const int per = (nb + T - 1) / T;
+        if (per * r > EMAX) return false;
+    }
+    return true;
+}
+
+inline bool plan_shape(int N, int& T, std::vector<int>& radices) {
+    if (N < 1 || N > EMAX * 1024) return false;
+    int t0 = ((N + EMAX - 1) / EMAX + 63) / 64 * 64;
+    if (t0 < 64) t0 = 64;
+    for (T = t0; T <= 1024; T += 64)
+        if (plan_radices(N, T, radices)) return true;
+    return false;
+}
+
+struct Buffer {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfEntry { std::string name; uint64_t launches = 0; double ms = 0; };
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// what one pair merge needs besides its two inputs
+struct PairOut {
+    void* out = nullptr; int out_mode = OUT_F32;
+    const void* base = nullptr; int base_dtype = DT_BF16;
+    float post = 1.f;
+    int ifft_policy = 1;      // 1: NaN -> 0 and Inf -> error on the inverse transform's output (functions.py:211-217)
+};
+
+template <class B>
+class Pipeline {
+  public:
+    B be;
+    std::string err;
+    void* stream = nullptr;
+
+    explicit Pipeline(int device) : be(device) {}
+    ~Pipeline() {
+        for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
+        for (Buffer* b : {&t1_, &planes_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        for (Buffer& b : inter_) if (b.p) be.free(b.p);
+    }
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+
+    // ---- plans ---------------------------------------------------------------
+    int get_plan(int N, FftPlanDev& out) {
+        auto it = plans_.find(N);
+        if (it == plans_.end()) {
+            HostPlan hp;
+            int T;
+            std::vector<int> rad;
+            if (plan_shape(N, T, rad)) {
+                hp.ok = true;
+                hp.dev.N = N; hp.dev.T = T; hp.dev.npass = (int)rad.size();
+                for (int i = 0; i < MAX_PASSES; ++i) hp.dev.radix[i] = i < (int)rad.size() ? rad[i] : 1;
+                hp.dev.lds_floats = (int)round_up((size_t)lpad(N) + 1, 32);
+                std::vector<cf2> tw(N);
+                for (int j = 0; j < N; ++j) {
+                    const double ang = -2.0 * M_PI * (double)j / (double)N;
+                    tw[j].x = (float)cos(ang); tw[j].y = (float)sin(ang);
+                }
+                void* d = be.alloc(sizeof(cf2) * N);
+                if (!d) return fail(SMHIP_ERR_NOMEM, "twiddle alloc failed");
+                be.h2d(d, tw.data(), sizeof(cf2) * N, stream);
+                hp.dev.tw = (const cf2*)d;
+            } else {
+                hp.dev.tw = nullptr;
+            }
+            it = plans_.emplace(N, hp).first;
+        }
+        if (!it->second.ok) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "unsupported transform length %d (needs factors in {2,3,5,7,11,13} and <= %d)", N, EMAX * 1024);
+            return fail(SMHIP_ERR_SHAPE, buf);
+        }
+        out = it->second.dev;
+        return SMHIP_OK;
+    }
+
+    // ---- workspace -------------------------------------------------------------
+    int ensure(Buffer& b, size_t bytes) {
+        if (b.cap >= bytes) return SMHIP_OK;
+        if (b.p) { be.sync(stream); be.free(b.p); b.p = nullptr; b.cap = 0; }
+        b.p = be.alloc(bytes);
+        if (!b.p) return fail(SMHIP_ERR_NOMEM, "workspace allocation failed");
+        b.cap = bytes;
+        return SMHIP_OK;
+    }
+    size_t workspace_bytes() const {
+        size_t t = t1_.cap + planes_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
+        for (const Buffer& b : inter_) t += b.cap;
+        return t;
+    }
+
+    struct Geo {
+        int R, C, Cb, pitch4, pitchG;
+        size_t plane_floats;      // one plane, padded
+        bool full;                // planes hold the full spectrum (weights 1)
+        int Cw;                   // C passed to bin_weight (-1 in full mode)
+    };
+    Geo geo(int R, int C, bool full = false) const {
+        Geo g;
+        g.R = R; g.C = C; g.full = full;
+        g.Cb = full ? C : C / 2 + 1;
+        g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
+        g.pitchG = 2 * g.pitch4;
+        g.plane_floats = round_up((size_t)g.Cb * R, 64);
+        g.Cw = full ? -1 : C;
+        return g;
+    }
+    static constexpr int MAXGRID_PART = 1 << 20;
+    int reserve(int R, int C, bool full = false) {
+        const Geo g = geo(R, C, full);
+        int rc;
+        if ((rc = ensure(t1_, (size_t)R * g.pitch4 * sizeof(cf4)))) return rc;
+        if ((rc = ensure(planes_, 4 * g.plane_floats * sizeof(float)))) return rc;
+        if (!small_.p) {
+            if ((rc = ensure(small_, SMALL_BYTES))) return rc;
+            be.memset(small_.p, 0, SMALL_BYTES, stream);
+        }
+        return SMHIP_OK;
+    }
+    // small device block layout
+    static constexpr size_t OFF_HIST = 0;                                  // u64[2048]
+    static constexpr size_t OFF_SEL = OFF_HIST + 8 * HIST1_BINS;           // SelState[2]
+    static constexpr size_t OFF_CONSTS = OFF_SEL + 2 * sizeof(SelState);   // BlendConsts
+    static constexpr size_t OFF_THR = OFF_CONSTS + 256;                    // float thr[4]
+    static constexpr size_t OFF_FLAGS = OFF_THR + 64;                      // u32[8]
+    static constexpr size_t OFF_PART = OFF_FLAGS + 64;                     // double partials
+    static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
+    static constexpr size_t SMALL_BYTES = OFF_PART + PART_DOUBLES * 8;
+    unsigned long long* d_hist() { return (unsigned long long*)((char*)small_.p + OFF_HIST); }
+    SelState* d_sel(int i) { return (SelState*)((char*)small_.p + OFF_SEL) + i; }
+    BlendConsts* d_consts() { return (BlendConsts*)((char*)small_.p + OFF_CONSTS); }
+    float* d_thr(int i) { return (float*)((char*)small_.p + OFF_THR) + i; }
+    uint32_t* d_flags() { return (uint32_t*)((char*)small_.p + OFF_FLAGS); }
+    double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
+    float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
+    enum { P_REA = 0, P_IMA = 1, P_REB = 2, P_RER = 3 };
+
+    // ---- stages ------------------------------------------------------------------
+    static int stream_grid(size_t units, int block, int chunks) {
+        const size_t per = (size_t)block * chunks;
+        size_t g = (units + per - 1) / per;
+        return (int)std::max<size_t>(g, 1);
+    }
+    static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+    static int vec4(const Geo& g) { return g.full ? (((size_t)g.R * g.C) % 4 == 0) : (g.R % 4 == 0); }
+
+    // F1: T1 <- row spectra of (a, b); per-group sums of squares land in d_part()
+    int run_f1(const Geo& g, const SigDesc& a, const SigDesc& b, int& grid_out) {
+        F1Params p;
+        int rc = get_plan(g.C, p.plan);
+        if (rc) return rc;
+        p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4;
+        p.nb = std::max(1, 256 / p.plan.T);
+        p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        p.t1 = (cf4*)t1_.p;
+        p.partials = d_part();
+        const int grid = (g.R + p.nb - 1) / p.nb;
+        if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
+        be.template launch<KF1>(grid, p.nb * p.plan.T, lds, p, stream);
+        grid_out = grid;
+        return SMHIP_OK;
+    }
+    void read_norms(int grid, double& na, double& nb) {
+        host_part_.resize((size_t)grid * 2);
+        be.d2h(host_part_.data(), d_part(), sizeof(double) * grid * 2, stream);
+        double sa = 0, sb = 0;
+        for (int i = 0; i < grid; ++i) { sa += host_part_[2 * i]; sb += host_part_[2 * i + 1]; }
+        na = std::sqrt(sa); nb = std::sqrt(sb);
+    }
+
+    int run_f2(const Geo& g, float scale0, float scale1, int swap, bool hist) {
+        F2Params p;
+        int rc = get_plan(g.R, p.plan);
+        if (rc) return rc;
+        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
+        p.nsig = (2 * p.plan.T <= 1024) ? 2 : 1;
+        p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
+        p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
+        p.hist = hist ? d_hist() : nullptr;
+        const int grid = p.Cb * (p.nsig == 2 ? 1 : 2);
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nsig * p.plan.lds_floats + HIST1_BINS) * 4;
+        be.template launch<KF2>(grid, p.nsig * p.plan.T, lds, p, stream);
+        return SMHIP_OK;
+    }
+
+    // exact k-th smallest of |X| (and |Y|) with bin multiplicities -> *thr_out
+    void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out) {
+        const size_t total = (size_t)g.Cb * g.R;
+        HistParams h;
+        h.X = X; h.Y = Y; h.R = g.R; h.C = g.Cw; h.Cb = g.Cb; h.vec4 = vec4(g); h.sel = d_sel(0);
+        h.hist = d_hist(); h.chunks = 8;
+        const int hgrid = stream_grid((total + 3) / 4, 256, h.chunks);
+        const size_t hlds = (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4;
+        ScanParams s;
+        s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out;
+        if (!level1_done) { h.level = 1; be.template launch<KHist>(hgrid, 256, hlds, h, stream); }
+        s.nbins = HIST1_BINS; s.shift = 11; s.final_level = 0; s.init = 1; s.rank_init = rank;
+        be.template launch<KScan>(1, 256, (LDS_SCRATCH_FLOATS + 2 * 256) * 4, s, stream);
+        for (int level = 2; level <= 3; ++level) {
+            h.level = level;
+            be.template launch<KHist>(hgrid, 256, hlds, h, stream);
+            s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = (level == 3); s.init = 0;
+            be.template launch<KScan>(1, 256, (LDS_SCRATCH_FLOATS + 2 * 256) * 4, s, stream);
+        }
+    }
+
+    void run_blend(const Geo& g, int mode, int agreement, float t, float t_sum, bool hist) {
+        const size_t total = (size_t)g.Cb * g.R;
+        BlendParams b;
+        b.reA = plane(g, P_REA); b.reB = plane(g, P_REB); b.reR = plane(g, P_RER);
+        b.R = g.R; b.C = g.Cw; b.Cb = g.Cb; b.vec4 = vec4(g);
+        b.mode = mode; b.agreement = agreement; b.t = t; b.t_sum = t_sum;
+        b.consts = d_consts(); b.hist = hist ? d_hist() : nullptr; b.chunks = 8;
+        be.template launch<KBlend>(stream_grid((total + 3) / 4, 256, b.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, b, stream);
+    }
+
+    // masked slerp sums + constants (reference functions.py:36-43 on the slerp class)
+    void run_slerp_consts(const Geo& g, bool have_thr, float t) {
+        const size_t total = (size_t)g.Cb * g.R;
+        ReduceParams r;
+        r.reA = plane(g, P_REA); r.reB = plane(g, P_REB); r.R = g.R; r.C = g.Cw; r.Cb = g.Cb; r.vec4 = vec4(g);
+        r.thr = have_thr ? d_thr(0) : nullptr; r.partials = d_part(); r.chunks = 16;
+        int grid = stream_grid((total + 3) / 4, 256, r.chunks);
+        while ((size_t)grid * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
+        be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
+        SlerpConstParams c;
+        c.partials = d_part(); c.nparts = grid; c.thr = r.thr; c.t = t; c.out = d_consts();
+        be.template launch<KSlerpConsts>(1, 64, LDS_SCRATCH_FLOATS * 4, c, stream);
+    }
+
+    int run_inverse(const Geo& g, const float* reR, const float* imA, const float* cull_thr, const PairOut& o) {
+        I1Params a;
+        int rc = get_plan(g.R, a.plan);
+        if (rc) return rc;
+        const int Cb = g.C / 2 + 1;
+        a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.R = g.R; a.Cb = Cb;
+        a.s = (2 * a.plan.T <= 1024) ? 2 : 1;
+        a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
+        const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
+        const int grid1 = (Cb + a.s - 1) / a.s;
+        if (a.s == 2) be.template launch<KI1x2>(grid1, 2 * a.plan.T, lds1, a, stream);
+        else be.template launch<KI1x1>(grid1, a.plan.T, lds1, a, stream);
+
+        I2Params b;
+        if ((rc = get_plan(g.C, b.plan))) return rc;
+        b.G = (const cf2*)t1_.p; b.pitchG = g.pitchG; b.R = g.R; b.C = g.C; b.Cb = Cb;
+        b.nb = std::max(1, 256 / b.plan.T);
+        b.vec = (g.C % 8 == 0) && aligned16(o.out) && aligned16(o.base);
+        b.inv_n = (float)(1.0 / ((double)g.R * (double)g.C));
+        b.ifft_policy = o.ifft_policy;
+        b.post = o.post; b.base = o.base; b.base_dtype = o.base_dtype; b.out = o.out; b.out_mode = o.out_mode;
+        b.flags = d_flags();
+        const int pairs = (g.R + 1) / 2;
+        const int grid2 = (pairs + b.nb - 1) / b.nb;
+        const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
+        be.template launch<KI2>(grid2, b.nb * b.plan.T, lds2, b, stream);
+        return SMHIP_OK;
+    }
+
+    // out = ca*a + cb*b (+ base, NaN/Inf policy, cast), optional sums of squares
+    void run_combine(const SigDesc& a, const SigDesc& b, float ca, float cb, size_t n, float* out_f32,
+                     const PairOut* fin, bool want_norms, int* grid_out = nullptr) {
+        CombineParams c;
+        c.a = a; c.b = b; c.ca = ca; c.cb = cb; c.n = n; c.out_f32 = out_f32;
+        c.base = fin ? fin->base : nullptr; c.base_dtype = fin ? fin->base_dtype : DT_BF16;
+        c.out_final = fin ? fin->out : nullptr; c.out_mode = fin ? fin->out_mode : OUT_F32;
+        c.flags = d_flags();
+        c.vec8 = (n % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base) &&
+                 aligned16(out_f32) && aligned16(c.base) && aligned16(c.out_final);
+        c.chunks = 4;
+        int grid = stream_grid((n + 7) / 8, 256, c.chunks);
+        while ((size_t)grid * 2 > PART_DOUBLES) { c.chunks *= 2; grid = stream_grid((n + 7) / 8, 256, c.chunks); }
+        c.partials = want_norms ? d_part() : nullptr;
+        be.template launch<KCombine>(grid, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
+        if (grid_out) *grid_out = grid;
+    }
+
+    void read_blend_info(smhip_blend_info* info, bool have_cut, bool have_cull, bool have_consts) {
+        if (!info) return;
+        BlendConsts c;
+        float thr[4];
+        be.d2h(&c, d_consts(), sizeof c, stream);
+        be.d2h(thr, d_thr(0), sizeof thr, stream);
+        info->cutoff_threshold = have_cut ? thr[0] : 0.0;
+        info->cull_threshold = have_cull ? thr[1] : 0.0;
+        info->dot = have_consts ? c.dot : 0.0;
+        info->s00 = have_consts ? c.s00 : 0.0; info->s01 = have_consts ? c.s01 : 0.0; info->s11 = have_consts ? c.s11 : 0.0;
+        info->n_slerp = have_consts ? c.n_slerp : 0;
+    }
+
+    static unsigned long long pct_index(unsigned long long len, double pct) {
+        // Python: int(len(all_real) * pct), clamped to the last element (functions.py:115-119)
+        unsigned long long idx = (unsigned long long)((double)len * pct);
+        if (idx >= len) idx = len - 1;
+        return idx;
+    }
+
+    // spectrum-domain part of a pair merge; planes P_REA/P_IMA/P_REB already hold
+    // the (scaled) half spectra.  Leaves Re R in P_RER and the cull threshold in d_thr(1).
+    void spectral_blend(const Geo& g, int mode, double t, double t_sum, double cutoff_pct, double cull_pct,
+                        int agreement, bool level1_hist_done, bool& have_cull) {
+        const unsigned long long nfull = g.full ? (unsigned long long)g.R * g.C : (unsigned long long)g.R * g.C;
+        have_cull = false;
+        if (mode == BLEND_SLERP) {
+            const bool have_cut = cutoff_pct > 0;
+            if (have_cut)
+                run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0));
+            run_slerp_consts(g, have_cut, (float)t);
+            run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
+            if (cull_pct > 0) {
+                run_select(g, plane(g, P_RER), nullptr, pct_index(nfull, cull_pct), true, d_thr(1));
+                have_cull = true;
+            }
+        } else {
+            run_blend(g, BLEND_ARITH, agreement, (float)t, 1.f, false);
+        }
+    }
+
+    // ---- A9: merge_tensors_fft2_slerp on fp32 inputs ---------------------------------
+    int merge_pair_slerp(const float* v0, const float* v1, int R, int C, double t, double bthr, double t_sum,
+                         double cutoff_pct, double cull_pct, float* out, double* n0o, double* n1o, int* branch,
+                         smhip_blend_info* info) {
+        const Geo g = geo(R, C);
+        int rc = reserve(R, C);
+        if (rc) return rc;
+        be.memset(d_flags(), 0, 32, stream);
+        SigDesc a{v0, nullptr, DT_F32, 1.f}, b{v1, nullptr, DT_F32, 1.f};
+        int grid;
+        if ((rc = run_f1(g, a, b, grid))) return rc;
+        double n0, n1;
+        read_norms(grid, n0, n1);
+        // reference normalises in fp32: norm().item() is an fp32 value
+        n0 = (double)(float)n0; n1 = (double)(float)n1;
+        if (n0o) *n0o = n0;
+        if (n1o) *n1o = n1;
+        const size_t n = (size_t)R * C;
+        if (n1 < 1e-4 || n0 < 1e-4) {              // functions.py:184-190: normalised v0 comes back
+            if (branch) *branch = SMHIP_BRANCH_EARLY_V0;
+            SigDesc none{nullptr, nullptr, DT_F32, 1.f};
+            run_combine(a, none, n0 != 0 ? (float)(1.0 / n0) : 1.f, 0.f, n, out, nullptr, false);
+            read_blend_info(info, false, false, false);
+            return SMHIP_OK;
+        }
+        const double ratio = n1 / (n0 + 1e-10);
+        PairOut po;
+        po.out = out; po.out_mode = OUT_F32; po.post = 1.f;
+        if (ratio < bthr) {
+            // functions.py:199-202: R = F0 + t*F1, Im included: linear in the spectrum.
+            if (branch) *branch = SMHIP_BRANCH_LINEAR;
+            if ((rc = run_f2_linear(g, (float)(1.0 / n0), (float)(1.0 / n1), (float)t))) return rc;
+            if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), nullptr, po))) return rc;
+            read_blend_info(info, false, false, false);
+            return check_flags(true, false);
+        }
+        if (branch) *branch = SMHIP_BRANCH_SLERP;
+        if ((rc = run_f2(g, (float)(1.0 / n0), (float)(1.0 / n1), 0, cutoff_pct > 0))) return rc;
+        bool have_cull;
+        spectral_blend(g, BLEND_SLERP, t, t_sum, cutoff_pct, cull_pct, 1, true, have_cull);
+        if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, po))) return rc;
+        read_blend_info(info, cutoff_pct > 0, have_cull, true);
+        return check_flags(true, false);
+    }
+
+    // ratio < b path: spectra added with weight t (needs Im of both inputs): do it in
+    // the spectral domain exactly as the reference: Re R = ra + t rb, Im R = ia + t ib.
+    int run_f2_linear(const Geo& g, float s0, float s1, float t) {
+        // Im b is not kept by F2, so run F2 twice with roles swapped: first pass
+        // leaves (Re a, Im a, Re b); second pass with swap=1 leaves Im b in P_IMA.
+        int rc = run_f2(g, s0, s1, 0, false);
+        if (rc) return rc;
+        const size_t total = (size_t)g.Cb * g.R;
+        // Re R = ra + t*rb  (arithmetic blend without agreement)
+        run_blend(g, BLEND_ARITH, 0, t, 1.f, false);
+        // keep Im a in tmp, fetch Im b, then Im R = ia + t*ib
+        if ((rc = ensure(tmpC_, g.plane_floats * sizeof(float)))) return rc;
+        SigDesc ia{plane(g, P_IMA), nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+        run_combine(ia, none, 1.f, 0.f, total, (float*)tmpC_.p, nullptr, false);
+        // second F2 with swapped roles overwrites P_REA/P_IMA with b's planes and P_REB with a's
+        if ((rc = run_f2(g, s0, s1, 1, false))) return rc;
+        SigDesc ib{plane(g, P_IMA), nullptr, DT_F32, 1.f}, ia2{tmpC_.p, nullptr, DT_F32, 1.f};
+        run_combine(ia2, ib, 1.f, t, total, plane(g, P_IMA), nullptr, false);
+        return SMHIP_OK;
+    }
+
+    void clear_flags() { be.memset(d_flags(), 0, 32, stream); }
+
+    int check_flags(bool ifft_stage, bool final_stage, uint32_t* nan_ifft = nullptr, uint32_t* nan_final = nullptr) {
+        uint32_t f[8];
+        be.d2h(f, d_flags(), sizeof f, stream);
+        if (nan_ifft) *nan_ifft = f[0];
+        if (nan_final) *nan_final = f[2];
+        if (ifft_stage && f[1]) return fail(SMHIP_ERR_INF_IFFT, "Inf in ifft output");
+        if (final_stage && f[3]) return fail(SMHIP_ERR_INF_MERGED, "Inf in merged tensor");
+        return SMHIP_OK;
+    }
+
+    // ---- A10: task_arithmetic_fft2 on fp32 inputs ------------------------------------
+    int pair_arith(const SigDesc& a_in, const SigDesc& b_in, int R, int C, float sa, float sb, double t, int agreement,
+                   const PairOut& po, double na_hint, double nb_hint) {
+        const Geo g = geo(R, C);
+        int rc = reserve(R, C);
+        if (rc) return rc;
+        SigDesc a = a_in, b = b_in;
+        int grid;
+        // two-for-one packs a and b into one complex transform: rounding noise of the
+        // larger contaminates the smaller at ~1e-7 of the larger, so lift a tiny b by
+        // an exact power of two first (its sign pattern decides the blend, quirk Q3).
+        double na = na_hint, nb = nb_hint;
+        if (na < 0 || nb < 0) {
+            if ((rc = run_f1(g, a, b, grid))) return rc;
+            read_norms(grid, na, nb);
+            na *= std::fabs(sa); nb *= std::fabs(sb);
+        } else {
+            na *= std::fabs(sa); nb *= std::fabs(sb);
+            grid = -1;
+        }
+        float pre = 1.f;
+        if (nb > 0 && na > 0 && (nb < na * 0.25 || nb > na * 4.0)) {
+            int e;
+            std::frexp(na / nb, &e);
+            pre = std::ldexp(1.f, e - 1);
+        }
+        if (pre != 1.f || grid < 0) {
+            b.prescale = b_in.prescale * pre;
+            if ((rc = run_f1(g, a, b, grid))) return rc;
+        }
+        if ((rc = run_f2(g, sa, sb / pre, 0, false))) return rc;
+        bool have_cull;
+        spectral_blend(g, BLEND_ARITH, t, 1.0, 0, 0, agreement, false, have_cull);
+        return run_inverse(g, plane(g, P_RER), plane(g, P_IMA), nullptr, po);
+    }
+
+    // ---- A1-A13: the layer tournament ---------------------------------------------------
+    // greedy pairing, reference functions.py:316-365 with way="least"
+    static void correlated_pairs_least(const std::vector<float>& norms, int m, std::vector<std::pair<int, int>>& out) {
+        out.clear();
+        std::vector<char> used(m, 0);
+        std::vector<float> corr((size_t)m * m, 0.f);
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) corr[(size_t)i * m + j] = norms[i] * norms[j];
+        for (;;) {
+            float best = INFINITY;
+            bool any = false;
+            for (int i = 0; i < m; ++i)
+                for (int j = i + 1; j < m; ++j)
+                    if (!used[i] && !used[j]) { any = true; best = std::min(best, std::fabs(corr[(size_t)i * m + j])); }
+            if (!any) break;
+            int bx = -1, by = -1;
+            for (int i = 0; i < m && bx < 0; ++i)
+                for (int j = i + 1; j < m; ++j)
+                    if (!used[i] && !used[j] && std::fabs(corr[(size_t)i * m + j]) == best) { bx = i; by = j; break; }
+            if (bx < 0) break;      // NaN norms: nothing compares equal (reference breaks too)
+            out.emplace_back(bx, by);
+            used[bx] = used[by] = 1;
+        }
+        for (int i = 0; i < m; ++i)
+            if (!used[i]) out.emplace_back(i, -1);
+    }
+
+    struct Slot {           // one entry of the reference's layer_stack
+        SigDesc sig;        // where its values live
+        double weight;
+        double norm;        // ||.||_2 if known, else < 0
+    };
+
+    int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
+        if (d.k < 1 || d.k > SMHIP_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
+        const int R = d.rows, C = d.cols;
+        if (R < 1 || C < 1) return fail(SMHIP_ERR_ARG, "bad shape");
+        const size_t n = (size_t)R * C;
+        const Geo g = geo(R, C);
+        int rc;
+        if (!small_.p && (rc = reserve(1, 1))) return rc;
+        be.memset(d_flags(), 0, 32, stream);
+        smhip_layer_report local;
+        smhip_layer_report& rp = rep ? *rep : local;
+        memset(&rp, 0, sizeof rp);
+        rp.merged_delta_norm = -1;
+
+        std::vector<Slot> stack(d.k);
+        for (int i = 0; i < d.k; ++i) {
+            stack[i].sig = SigDesc{d.finetune[i], d.base[i], d.in_dtype, 1.f};
+            stack[i].weight = d.alpha[i];
+            stack[i].norm = -1;
+        }
+        PairOut fin;
+        fin.out = out_bf16; fin.out_mode = OUT_BF16; fin.base = d.base_out; fin.base_dtype = d.base_out_dtype; fin.post = 1.f;
+
+        // K = 1: result = base_out + (ft - base)        (tournament loop is skipped)
+        if (d.k == 1) {
+            SigDesc none{nullptr, nullptr, DT_F32, 1.f};
+            int grid;
+            run_combine(stack[0].sig, none, 1.f, 0.f, n, delta_out, &fin, true, &grid);
+            double na, nb;
+            read_norms(grid, na, nb);
+            rp.delta_norm[0] = na; rp.target_norm = (double)(float)na + d.target_norm_offset; rp.merged_delta_norm = na;
+            return check_flags(false, true, &rp.nan_ifft, &rp.nan_final);
+        }
+        if ((rc = reserve(R, C))) return rc;
+
+        // norms of every delta.  K == 2: fused into the (speculative) F1 of the only pair.
+        std::vector<float> norms32(d.k);
+        int f1_grid = -1;
+        bool f1_ready = false;
+        if (d.k == 2) {
+            if ((rc = run_f1(g, stack[0].sig, stack[1].sig, f1_grid))) return rc;
+            double na, nb;
+            read_norms(f1_grid, na, nb);
+            stack[0].norm = na; stack[1].norm = nb;
+            f1_ready = true;
+        } else {
+            SigDesc none{nullptr, nullptr, DT_F32, 1.f};
+            for (int i = 0; i < d.k; i += 2) {
+                int grid;
+                const bool two = i + 1 < d.k;
+                run_combine(stack[i].sig, two ? stack[i + 1].sig : none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
+                double na, nb;
+                read_norms(grid, na, nb);
+                stack[i].norm = na;
+                if (two) stack[i + 1].norm = nb;
+            }
+        }
+        double mean = 0;
+        for (int i = 0; i < d.k; ++i) {
+            norms32[i] = (float)stack[i].norm;           // torch.norm of an fp32 tensor is fp32
+            rp.delta_norm[i] = norms32[i];
+        }
+        {   // torch.tensor(layer_norms).mean(): fp32 mean
+            float acc = 0.f;
+            for (int i = 0; i < d.k; ++i) acc += norms32[i];
+            mean = (double)(acc / (float)d.k);
+        }
+        const double target_norm = mean + d.target_norm_offset;
+        rp.target_norm = target_norm;
+        double cull_pct = d.cull_start_pct;
+
+        std::vector<char> inter_busy(inter_.size(), 0);
+        int step = 0;
+        while (stack.size() > 1) {
+            const int m = (int)stack.size();
+            std::vector<std::pair<int, int>> pairs;
+            correlated_pairs_least(norms32, m, pairs);   // Q1: first m entries of the ORIGINAL norm list
+            std::vector<Slot> next;
+            const bool last_round = (pairs.size() == 1 && pairs[0].second >= 0);
+            for (auto& pr : pairs) {
+                const int x = pr.first, y = pr.second;
+                if (step < SMHIP_MAX_PAIRS) { rp.step_x[step] = x; rp.step_y[step] = y; }
+                if (y < 0) {
+                    next.push_back(stack[x]);
+                    if (step < SMHIP_MAX_PAIRS) rp.step_branch[step] = SMHIP_BRANCH_CARRY;
+                    ++step;
+                    continue;
+                }
+                Slot A = stack[x], Bs = stack[y];
+                const double a_w = stack[x].weight, b_w = stack[y].weight;   // Q4: not swapped
+                if (A.norm < 0 || Bs.norm < 0) return fail(SMHIP_ERR_ARG, "internal: norm unknown");
+                double na = (double)(float)A.norm, nb = (double)(float)Bs.norm;
+                bool swapped = false;
+                if (std::fabs(na) < std::fabs(nb)) { std::swap(A, Bs); std::swap(na, nb); swapped = true; }
+                const double ca = std::fabs(na / target_norm), cb = std::fabs(nb / target_norm);
+                const double ratio = cb / (ca + 1e-10);
+                // destination: final output when this is the last merge, else an fp32 intermediate
+                PairOut po;
+                float* inter = nullptr;
+                if (last_round) {
+                    po = fin;
+                } else {
+                    int id = -1;
+                    for (size_t q = 0; q < inter_.size(); ++q) if (!inter_busy[q]) { id = (int)q; break; }
+                    if (id < 0) { inter_.emplace_back(); inter_busy.push_back(0); id = (int)inter_.size() - 1; }
+                    Buffer* bb = &inter_[id];
+                    if ((rc = ensure(*bb, n * sizeof(float)))) return rc;
+                    inter_busy[id] = 1;
+                    inter = (float*)bb->p;
+                    po.out = inter; po.out_mode = OUT_F32; po.post = 1.f;
+                }
+                int branch;
+                smhip_blend_info info;
+                memset(&info, 0, sizeof info);
+                double out_norm = -1;
+                if (ca < 1e-6) {
+                    branch = SMHIP_BRANCH_ADD;                       // merged = a + b
+                    int grid;
+                    if (last_round) run_combine(A.sig, Bs.sig, 1.f, 1.f, n, delta_out, &po, false, &grid);
+                    else run_combine(A.sig, Bs.sig, 1.f, 1.f, n, inter, nullptr, false, &grid);
+                } else if (cb < 1e-6 || ratio < 0.1) {
+                    branch = SMHIP_BRANCH_ARITH;
+                    const double s = target_norm / na;
+                    const double w = b_w / (a_w + 1e-10);
+                    PairOut pa = po;
+                    float* dtmp = nullptr;
+                    if (last_round && delta_out) { pa = PairOut(); pa.out = delta_out; dtmp = delta_out; }
+                    pa.ifft_policy = 0;
+                    if ((rc = pair_arith(A.sig, Bs.sig, R, C, (float)s, (float)(w * s), 1.0, 1, pa, na, nb))) return rc;
+                    if (dtmp) {     // add-back from the fp32 delta
+                        SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+                        run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
+                    }
+                    f1_ready = false;
+                } else {
+                    branch = SMHIP_BRANCH_SLERP;
+                    const double t = a_w / (a_w + b_w);
+                    // merge_tensors_fft2_slerp early-outs on the fp32 norms (functions.py:184-190)
+                    if (nb < 1e-4 || na < 1e-4) {
+                        SigDesc none{nullptr, nullptr, DT_F32, 1.f};
+                        const float sc = (float)(target_norm / na);
+                        if (last_round) run_combine(A.sig, none, sc, 0.f, n, delta_out, &po, false);
+                        else run_combine(A.sig, none, sc, 0.f, n, inter, nullptr, false);
+                        branch = SMHIP_BRANCH_EARLY_V0;
+                    } else {
+                        if (!(f1_ready && d.k == 2)) {
+                            int grid;
+                            if ((rc = run_f1(g, stack[x].sig, stack[y].sig, grid))) return rc;
+                        }
+                        f1_ready = false;
+                        // T1 slot 0 holds stack[x], slot 1 holds stack[y]; role "a" is the larger norm
+                        const float s0 = (float)(1.0 / (double)(float)stack[x].norm);
+                        const float s1 = (float)(1.0 / (double)(float)stack[y].norm);
+                        if ((rc = run_f2(g, s0, s1, swapped ? 1 : 0, d.cutoff_pct > 0))) return rc;
+                        bool have_cull;
+                        spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull);
+                        PairOut ps = po;
+                        ps.post = (float)target_norm;                       // merged * target_norm (fast_fourier.py:243)
+                        float* dtmp = nullptr;
+                        if (last_round && delta_out) { ps = PairOut(); ps.out = delta_out; ps.post = (float)target_norm; dtmp = delta_out; }
+                        if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, ps))) return rc;
+                        if (dtmp) {
+                            SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+                            run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
+                        }
+                        read_blend_info(&info, d.cutoff_pct > 0, have_cull, true);
+                    }
+                }
+                if (step < SMHIP_MAX_PAIRS) { rp.step_branch[step] = branch; rp.step_info[step] = info; }
+                ++step;
+                for (size_t q = 0; q < inter_.size(); ++q)     // inputs that were intermediates are dead now
+                    if (inter_[q].p && (inter_[q].p == stack[x].sig.x || inter_[q].p == stack[y].sig.x)) inter_busy[q] = 0;
+                if (!last_round) {
+                    // the next round needs ||merged|| (fast_fourier.py:209-210)
+                    SigDesc ms{inter, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+                    int grid;
+                    run_combine(ms, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
+                    double nm, dummy;
+                    read_norms(grid, nm, dummy);
+                    out_norm = nm;
+                    Slot s;
+                    s.sig = ms; s.weight = (a_w + b_w) / 2.0; s.norm = out_norm;
+                    next.push_back(s);
+                }
+            }
+            stack.swap(next);
+            cull_pct = cull_pct / 2.0;
+            if (last_round) break;
+        }
+        rp.n_steps = std::min(step, (int)SMHIP_MAX_PAIRS);
+        if (delta_out) {
+            SigDesc ds{delta_out, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+            int grid;
+            run_combine(ds, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
+            double nm, dummy;
+            read_norms(grid, nm, dummy);
+            rp.merged_delta_norm = nm;
+        }
+        return check_flags(true, true, &rp.nan_ifft, &rp.nan_final);
+    }
+
+    // ---- transforms for the function-level API -----------------------------------------
+    int fft_transform(const float* x, int R, int C, float* spectrum) {
+        const Geo g = geo(R, C);
+        int rc = reserve(R, C);
+        if (rc) return rc;
+        SigDesc a{x, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+        int grid;
+        if ((rc = run_f1(g, a, none, grid))) return rc;
+        if ((rc = run_f2(g, 1.f, 1.f, 0, false))) return rc;
+        ExpandParams e;
+        e.re = plane(g, P_REA); e.im = plane(g, P_IMA); e.R = R; e.C = C; e.Cb = g.Cb; e.full = (cf2*)spectrum; e.chunks = 8;
+        be.template launch<KExpand>(stream_grid((size_t)R * C, 256, e.chunks), 256, LDS_SCRATCH_FLOATS * 4, e, stream);
+        return SMHIP_OK;
+    }
+    // real part of the inverse transform of an arbitrary complex spectrum:
+    // Hermitian-symmetrise while packing, then the c2r inverse.
+    int ifft_transform(const float* spectrum, int R, int C, float* out) {
+        const Geo g = geo(R, C);
+        int rc = reserve(R, C);
+        if (rc) return rc;
+        be.memset(d_flags(), 0, 32, stream);
+        PackParams pk;
+        pk.full = (const cf2*)spectrum; pk.R = R; pk.C = C; pk.Cb = g.Cb; pk.re = plane(g, P_RER); pk.im = plane(g, P_IMA);
+        pk.chunks = 8; pk.sym = 1;
+        be.template launch<KPack>(stream_grid((size_t)g.Cb * R, 256, pk.chunks), 256, LDS_SCRATCH_FLOATS * 4, pk, stream);
+        PairOut po;
+        po.out = out; po.out_mode = OUT_F32; po.post = 1.f;
+        return run_inverse(g, plane(g, P_RER), plane(g, P_IMA), nullptr, po);
+    }
+
+    // A5-A7 on full complex spectra [R][C] (no Hermitian assumption: every bin has
+    // weight 1 and the planes simply keep the row-major order of the input).
+    int blend_full(const float* f0, const float* f1, int R, int C, int mode, double t, double t_sum, double cutoff_pct,
+                   double cull_pct, int agreement, int do_imag, float* out_spec, smhip_blend_info* info) {
+        const Geo g = geo(R, C, true);
+        int rc = reserve(R, C, true);
+        if (rc) return rc;
+        const size_t total = (size_t)R * C;
+        const int sgrid = stream_grid(total, 256, 8);
+        const size_t slds = LDS_SCRATCH_FLOATS * 4;
+        if ((rc = ensure(fullS_, 2 * total * sizeof(float)))) return rc;
+        float* im0 = (float*)fullS_.p;
+        float* im1 = im0 + total;
+        SplitParams sp;
+        sp.n = total; sp.chunks = 8;
+        sp.full = (const cf2*)f0; sp.re = plane(g, P_REA); sp.im = im0;
+        be.template launch<KSplit>(sgrid, 256, slds, sp, stream);
+        sp.full = (const cf2*)f1; sp.re = plane(g, P_REB); sp.im = im1;
+        be.template launch<KSplit>(sgrid, 256, slds, sp, stream);
+        bool have_cull;
+        spectral_blend(g, mode, t, t_sum, cutoff_pct, cull_pct, agreement, false, have_cull);
+        if (have_cull) {   // Re R[|Re R| < thr] = 0   (functions.py:147)
+            CullParams cp;
+            cp.x = plane(g, P_RER); cp.n = total; cp.thr = d_thr(1); cp.chunks = 8;
+            be.template launch<KCull>(sgrid, 256, slds, cp, stream);
+        }
+        read_blend_info(info, mode == BLEND_SLERP && cutoff_pct > 0, have_cull, mode == BLEND_SLERP);
+        JoinParams jp;
+        jp.n = total; jp.chunks = 8; jp.full = (cf2*)out_spec;
+        if (!do_imag) {
+            jp.re = plane(g, P_RER); jp.im = im0;
+            be.template launch<KJoin>(sgrid, 256, slds, jp, stream);
+            return SMHIP_OK;
+        }
+        // imaginary detour (functions.py:152-158 / :290-298): transform both imaginary
+        // planes, blend them with interp_imag / do_imag = False, inverse, keep .real
+        if ((rc = ensure(saveR_, total * sizeof(float)))) return rc;
+        if ((rc = ensure(saveI_, total * sizeof(float)))) return rc;
+        if ((rc = ensure(tmpA_, 2 * total * sizeof(float)))) return rc;
+        if ((rc = ensure(tmpB_, 2 * total * sizeof(float)))) return rc;
+        if ((rc = ensure(tmpC_, 2 * total * sizeof(float)))) return rc;
+        SigDesc rr{plane(g, P_RER), nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+        run_combine(rr, none, 1.f, 0.f, total, (float*)saveR_.p, nullptr, false);
+        if ((rc = fft_transform(im0, R, C, (float*)tmpA_.p))) return rc;
+        if ((rc = fft_transform(im1, R, C, (float*)tmpB_.p))) return rc;
+        if ((rc = blend_full((const float*)tmpA_.p, (const float*)tmpB_.p, R, C, mode, t, 1.0, 0, 0, agreement, 0,
+                             (float*)tmpC_.p, nullptr))) return rc;
+        if ((rc = ifft_transform((const float*)tmpC_.p, R, C, (float*)saveI_.p))) return rc;
+        jp.re = (const float*)saveR_.p; jp.im = (const float*)saveI_.p;
+        be.template launch<KJoin>(sgrid, 256, slds, jp, stream);
+        return SMHIP_OK;
+    }
+
+    // profiling table lives in the backend
+  private:
+    std::map<int, HostPlan> plans_;
+    Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_;
+    std::vector<Buffer> inter_;
+    std::vector<double> host_part_;
+};
+
+}  // namespace smhip

@@ -1,0 +1,255 @@
+"""Engine: torch-tensor front end of the C ABI (include/shardmerge_hip.h).
+
+PyTorch is used here for device memory and streams only: tensors are handed to
+the HIP library as raw device pointers (``Tensor.data_ptr()``) together with the
+current HIP stream; every transform, order statistic, blend and cast runs in the
+hand-written gfx950 kernels behind ``libshardmerge_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BlendInfo, Context, LayerDesc, LayerReport, SmhipError, SmhipLibrary
+
+logger = logging.getLogger(__name__)
+
+_DTYPE_CODE = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.F32}
+
+
+def _raise_like_reference(e: SmhipError, layer_name: Optional[str] = None):
+    """Map C-ABI status codes to the exceptions the reference raises."""
+    if e.code == _lib.ERR_INF_IFFT:
+        raise ValueError("Inf in ifft output") from e                      # functions.py:217
+    if e.code == _lib.ERR_INF_MERGED:
+        raise ValueError(f"Inf in merged tensor for {layer_name}") from e  # fast_fourier.py:274
+    if e.code == _lib.ERR_SHAPE:
+        raise NotImplementedError(e.message) from e
+    raise e
+
+
+@dataclass
+class BlendReport:
+    cutoff_threshold: float = 0.0
+    cull_threshold: float = 0.0
+    dot: float = 0.0
+    s00: float = 0.0
+    s01: float = 0.0
+    s11: float = 0.0
+    n_slerp: int = 0
+
+    @classmethod
+    def from_c(cls, bi: BlendInfo) -> "BlendReport":
+        return cls(bi.cutoff_threshold, bi.cull_threshold, bi.dot, bi.s00, bi.s01, bi.s11, int(bi.n_slerp))
+
+
+@dataclass
+class LayerMergeReport:
+    target_norm: float = 0.0
+    delta_norms: List[float] = field(default_factory=list)
+    steps: List[Tuple[int, int, str]] = field(default_factory=list)   # (x, y, branch)
+    infos: List[BlendReport] = field(default_factory=list)
+    nan_ifft: int = 0
+    nan_final: int = 0
+    merged_delta_norm: float = -1.0
+
+    @property
+    def branches(self) -> List[str]:
+        return [s[2] for s in self.steps]
+
+
+def _shape2d(t: torch.Tensor) -> Tuple[int, int]:
+    if t.ndim == 1:
+        return 1, t.shape[0]
+    if t.ndim == 2:
+        return t.shape[0], t.shape[1]
+    # the reference transforms the last two dims of an N-D tensor; model weights are 1-D / 2-D
+    raise NotImplementedError(f"tensor of rank {t.ndim} is not supported by the HIP path")
+
+
+class Engine:
+    """One smhip context bound to one torch device."""
+
+    def __init__(self, lib: Optional[SmhipLibrary] = None, device: Optional[torch.device] = None):
+        if lib is None:
+            lib = _lib.get_lib()
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            if device.type != "cuda":
+                raise RuntimeError("the HIP library needs a cuda (ROCm) torch device")
+        self.lib = lib
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        index = self.device.index if self.device.type == "cuda" and self.device.index is not None else 0
+        self.ctx = Context(lib, index)
+
+    # -- plumbing ---------------------------------------------------------------
+    def _stream(self) -> Optional[int]:
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _dev(self, t: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        if t.device != self.device:
+            t = t.to(self.device)
+        return t.contiguous()
+
+    def _call(self, rc: int, layer_name: Optional[str] = None):
+        try:
+            self.ctx.check(rc)
+        except SmhipError as e:
+            _raise_like_reference(e, layer_name)
+
+    # -- A4 / A8 -----------------------------------------------------------------
+    def fft_transform(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._dev(x, torch.float32)
+        r, c = _shape2d(x)
+        out = torch.empty(x.shape + (2,), dtype=torch.float32, device=self.device)
+        self._call(self.lib.dll.smhip_fft_transform(self.ctx.h, x.data_ptr(), r, c, out.data_ptr(), self._stream()))
+        return torch.view_as_complex(out)
+
+    def ifft_transform(self, spec: torch.Tensor) -> torch.Tensor:
+        spec = self._dev(spec, torch.complex64)
+        r, c = _shape2d(spec)
+        sr = torch.view_as_real(spec)
+        out = torch.empty(spec.shape, dtype=torch.float32, device=self.device)
+        self._call(self.lib.dll.smhip_ifft_transform(self.ctx.h, sr.data_ptr(), r, c, out.data_ptr(), self._stream()))
+        return out
+
+    # -- A5 - A7 -------------------------------------------------------------------
+    def interpolate_fft_components(self, f0, f1, t, t_sum=1.0, cutoff_pct=0.0, cull_pct=0.0, interp_imag=True):
+        f0 = self._dev(f0, torch.complex64)
+        f1 = self._dev(f1, torch.complex64)
+        r, c = _shape2d(f0)
+        out = torch.empty(f0.shape + (2,), dtype=torch.float32, device=self.device)
+        info = BlendInfo()
+        self._call(self.lib.dll.smhip_interpolate_fft_components(
+            self.ctx.h, torch.view_as_real(f0).data_ptr(), torch.view_as_real(f1).data_ptr(), r, c,
+            float(t), float(t_sum), float(cutoff_pct), float(cull_pct), 1 if interp_imag else 0,
+            out.data_ptr(), C.byref(info), self._stream()))
+        return torch.view_as_complex(out), BlendReport.from_c(info)
+
+    def arithmetic_fft_components(self, f0, f1, t, agreement=True, do_imag=True):
+        f0 = self._dev(f0, torch.complex64)
+        f1 = self._dev(f1, torch.complex64)
+        r, c = _shape2d(f0)
+        out = torch.empty(f0.shape + (2,), dtype=torch.float32, device=self.device)
+        self._call(self.lib.dll.smhip_arithmetic_fft_components(
+            self.ctx.h, torch.view_as_real(f0).data_ptr(), torch.view_as_real(f1).data_ptr(), r, c,
+            float(t), 1 if agreement else 0, 1 if do_imag else 0, out.data_ptr(), self._stream()))
+        return torch.view_as_complex(out)
+
+    # -- A9 / A10 ------------------------------------------------------------------
+    def merge_tensors_fft2_slerp(self, v0, v1, t, b=0.1, t_sum=1.0, cutoff_pct=0.0, cull_pct=0.0):
+        v0 = self._dev(v0, torch.float32)
+        v1 = self._dev(v1, torch.float32)
+        r, c = _shape2d(v0)
+        out = torch.empty_like(v0)
+        n0, n1, br = C.c_double(), C.c_double(), C.c_int()
+        info = BlendInfo()
+        self._call(self.lib.dll.smhip_merge_tensors_fft2_slerp(
+            self.ctx.h, v0.data_ptr(), v1.data_ptr(), r, c, float(t), float(b), float(t_sum), float(cutoff_pct),
+            float(cull_pct), out.data_ptr(), C.byref(n0), C.byref(n1), C.byref(br), C.byref(info), self._stream()))
+        rep = BlendReport.from_c(info)
+        rep.branch = _lib.BRANCH_NAMES.get(br.value, str(br.value))
+        return out, n0.value, n1.value, rep
+
+    def task_arithmetic_fft2(self, v0, v1, t, agreement=True):
+        v0 = self._dev(v0, torch.float32)
+        v1 = self._dev(v1, torch.float32)
+        r, c = _shape2d(v0)
+        out = torch.empty_like(v0)
+        self._call(self.lib.dll.smhip_task_arithmetic_fft2(
+            self.ctx.h, v0.data_ptr(), v1.data_ptr(), r, c, float(t), 1 if agreement else 0, out.data_ptr(), self._stream()))
+        return out
+
+    # -- A1 - A13 fused ------------------------------------------------------------------
+    def merge_layer(self, finetunes: Sequence[torch.Tensor], bases: Sequence[torch.Tensor], alphas: Sequence[float],
+                    base_out: torch.Tensor, target_norm_offset: float = 1e-10, cull_start_pct: float = 0.20,
+                    cutoff_pct: float = 0.08, t_sum: float = 1.0, want_delta: bool = False,
+                    layer_name: str = "layer"):
+        k = len(finetunes)
+        if k < 1 or k > _lib.MAX_MODELS:
+            raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
+        in_dtype = finetunes[0].dtype
+        if in_dtype not in _DTYPE_CODE:
+            in_dtype = torch.float32
+        keep = []           # keep device copies alive until the call returns
+        desc = LayerDesc()
+        desc.k = k
+        seen: Dict[int, torch.Tensor] = {}
+        for i in range(k):
+            ft = self._dev(finetunes[i], in_dtype)
+            bkey = id(bases[i])
+            if bkey not in seen:
+                seen[bkey] = self._dev(bases[i], in_dtype)
+            bs = seen[bkey]
+            if ft.shape != base_out.shape or bs.shape != base_out.shape:
+                raise ValueError(f"shape mismatch in {layer_name}: {tuple(ft.shape)} / {tuple(bs.shape)} / {tuple(base_out.shape)}")
+            keep += [ft, bs]
+            desc.finetune[i] = ft.data_ptr()
+            desc.base[i] = bs.data_ptr()
+            desc.alpha[i] = float(alphas[i])
+        bo_dtype = base_out.dtype if base_out.dtype in _DTYPE_CODE else torch.float32
+        bo = seen.get(id(base_out))
+        if bo is None or bo.dtype != bo_dtype:
+            bo = self._dev(base_out, bo_dtype)
+        keep.append(bo)
+        r, c = _shape2d(bo)
+        desc.in_dtype = _DTYPE_CODE[in_dtype]
+        desc.base_out = bo.data_ptr()
+        desc.base_out_dtype = _DTYPE_CODE[bo_dtype]
+        desc.rows, desc.cols = r, c
+        desc.target_norm_offset = float(target_norm_offset)
+        desc.cull_start_pct = float(cull_start_pct)
+        desc.cutoff_pct = float(cutoff_pct)
+        desc.t_sum = float(t_sum)
+        out = torch.empty(bo.shape, dtype=torch.bfloat16, device=self.device)
+        delta = torch.empty(bo.shape, dtype=torch.float32, device=self.device) if want_delta else None
+        rep = LayerReport()
+        self._call(self.lib.dll.smhip_merge_layer(self.ctx.h, C.byref(desc), out.data_ptr(),
+                                                  delta.data_ptr() if delta is not None else None,
+                                                  C.byref(rep), self._stream()), layer_name)
+        report = LayerMergeReport(
+            target_norm=rep.target_norm,
+            delta_norms=[rep.delta_norm[i] for i in range(k)],
+            steps=[(rep.step_x[i], rep.step_y[i], _lib.BRANCH_NAMES.get(rep.step_branch[i], "?")) for i in range(rep.n_steps)],
+            infos=[BlendReport.from_c(rep.step_info[i]) for i in range(rep.n_steps)],
+            nan_ifft=int(rep.nan_ifft), nan_final=int(rep.nan_final), merged_delta_norm=rep.merged_delta_norm)
+        if report.nan_ifft or report.nan_final:
+            logger.info(f"Warning: NaN replaced by 0 in {layer_name}: {report.nan_ifft} after ifft, {report.nan_final} after add-back")
+        if want_delta:
+            return out, report, delta
+        return out, report
+
+
+_engines: Dict[str, Engine] = {}
+
+
+def resolve_device(device) -> torch.device:
+    """'cuda', 'cuda:1', 'cpu' (ignored with a warning: this build computes on the GPU)."""
+    d = torch.device(device) if device is not None else torch.device("cuda")
+    if d.type != "cuda":
+        logger.warning("device=%s requested; shardmerge_amd computes on the MI355X (HIP) only - using cuda", device)
+        d = torch.device("cuda")
+    if d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
+def get_engine(device=None) -> Engine:
+    """Engine for a torch device; raises when the HIP library or a GPU is missing."""
+    _lib.get_lib()                                   # fail loudly before touching torch.cuda
+    if not torch.cuda.is_available():
+        raise RuntimeError("no ROCm GPU visible: shardmerge_amd has no CPU path")
+    d = resolve_device(device)
+    key = str(d)
+    if key not in _engines:
+        _engines[key] = Engine(device=d)
+    return _engines[key]

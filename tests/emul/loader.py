@@ -1,0 +1,33 @@
+"""Build (g++) and bind the CPU work-group emulator of the HIP kernels.
+TEST INFRASTRUCTURE ONLY - see smhip_emul.cpp."""
+import subprocess
+from pathlib import Path
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+SO = HERE / "libshardmerge_emul.so"
+CSRC = HERE.parents[1] / "shardmerge_amd" / "csrc"
+
+
+def build(force: bool = False) -> Path:
+    srcs = [HERE / "smhip_emul.cpp"] + sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + \
+           [HERE.parents[1] / "include" / "shardmerge_hip.h"]
+    newest = max(p.stat().st_mtime for p in srcs)
+    if force or not SO.exists() or SO.stat().st_mtime < newest:
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas",
+                        "-Wno-unused-variable", str(HERE / "smhip_emul.cpp"), "-o", str(SO)], check=True)
+    return SO
+
+
+_engine = None
+
+
+def emul_engine():
+    """Engine bound to the emulator; tensors live on the CPU."""
+    global _engine
+    if _engine is None:
+        from shardmerge_amd._lib import SmhipLibrary
+        from shardmerge_amd.engine import Engine
+        _engine = Engine(lib=SmhipLibrary(build()), device=torch.device("cpu"))
+    return _engine

@@ -1,0 +1,90 @@
+// smhip_emul.cpp - CPU work-group emulator of the HIP kernels (TEST INFRASTRUCTURE).
+//
+// Compiles the very same kernel bodies (shardmerge_amd/csrc/sm_kernels.hpp) and
+// the same host orchestration (sm_pipeline.hpp) with g++, running each
+// work-group's threads one after another between barriers.  It exists so that
+// the "not gpu" test tier can check indexing, planning and the tournament logic
+// of the product code in a container without a GPU.  It is never loaded by the
+// shardmerge_amd package (which binds libshardmerge_hip.so only and fails
+// loudly without it); only tests/ build and load it.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../shardmerge_amd/csrc/sm_pipeline.hpp"
+
+#define SM_VERSION_STRING "shardmerge-emul 0.1 (cpu work-group emulator, tests only)"
+
+namespace smhip {
+
+struct HostExec {
+    template <class S> struct State { using value_type = S; std::vector<S> v; };
+    int bid_, nt_;
+    std::vector<float>* lds_;
+    int bid() const { return bid_; }
+    int nthreads() const { return nt_; }
+    float* lds() { return lds_->data(); }
+    template <class S> void init(State<S>& st) { st.v.resize(nt_); }
+    template <class S, class F> void each(State<S>& st, F&& f) { for (int t = 0; t < nt_; ++t) f(t, st.v[t]); }
+    void sync() {}
+    void lds_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
+    void global_atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
+    void global_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
+    void global_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
+    template <int NV, class S, class F> void block_sum(State<S>& st, F&& f) {
+        double tot[NV];
+        for (int q = 0; q < NV; ++q) tot[q] = 0;
+        for (int t = 0; t < nt_; ++t)
+            for (int q = 0; q < NV; ++q) tot[q] += st.v[t].red[q];
+        f((const double*)tot);
+    }
+};
+
+struct HostBackend {
+    std::vector<ProfEntry> prof;
+    bool profiling = false;
+    explicit HostBackend(int) {}
+    bool ok() const { return true; }
+    std::string error() const { return ""; }
+    void* alloc(size_t n) { void* p = nullptr; if (posix_memalign(&p, 256, n ? n : 16)) return nullptr; ::memset(p, 0xCD, n); return p; }
+    void free(void* p) { ::free(p); }
+    void memset(void* p, int v, size_t n, void*) { ::memset(p, v, n); }
+    void sync(void*) {}
+    void d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); }
+    void h2d(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); }
+    template <class K>
+    void launch(int grid, int block, size_t lds_bytes, const typename K::Params& p, void*) {
+        if (lds_bytes > 160 * 1024) { fprintf(stderr, "emul: %s wants %zu bytes of LDS (> 160 KiB)\n", K::name(), lds_bytes); abort(); }
+        if (block > 1024 || block < 1) { fprintf(stderr, "emul: %s block size %d\n", K::name(), block); abort(); }
+        std::vector<float> lds(lds_bytes / 4 + 16);
+        for (int b = 0; b < grid; ++b) {
+            // poison LDS so that reads of never-written words show up as NaNs
+            for (auto& x : lds) x = std::nanf("");
+            HostExec ex{b, block, &lds};
+            K::run(ex, p);
+        }
+        if (profiling) {
+            ProfEntry* e = nullptr;
+            for (auto& q : prof) if (q.name == K::name()) e = &q;
+            if (!e) { prof.push_back(ProfEntry{K::name(), 0, 0.0}); e = &prof.back(); }
+            e->launches++;
+        }
+    }
+    void profile_enable(bool on) { profiling = on; }
+    void profile_reset() { prof.clear(); }
+    int profile_count() const { return (int)prof.size(); }
+    bool profile_get(int i, const char** name, uint64_t* launches, double* ms) const {
+        if (i < 0 || i >= (int)prof.size()) return false;
+        if (name) *name = prof[i].name.c_str();
+        if (launches) *launches = prof[i].launches;
+        if (ms) *ms = prof[i].ms;
+        return true;
+    }
+};
+
+}  // namespace smhip
+
+#define SM_BACKEND smhip::HostBackend
+#include "../../shardmerge_amd/csrc/sm_capi.inc"
