@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py - merged-weight GB/s of the spectral-merge hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3-8b|8192sq|llama3-70b-slice] [--k K]
+
+One "step" = one pass of the hot path (shardmerge_amd Engine.merge_layer through
+libshardmerge_hip.so: deltas -> forward 2-D FFT -> order statistics -> SLERP blend
+-> inverse FFT -> add-back -> bf16) over every block tensor of the workload, with
+all inputs already resident in HBM.  For N > 1 the driver launches one rank per
+GPU (torch.distributed.run); every rank merges its own, equally sized tensor list
+(weak scaling, no data-path collective); the shared base tensors are staged once
+with ONE RCCL broadcast from rank 0 before the timed region (reported as
+base_broadcast_ms).  Rank 0 prints one JSON line.
+
+value    = bytes of merged bf16 weights produced by ALL ranks / max-over-ranks time
+roofline = the dominant kernel's algorithmic bytes / its measured device time
+           (HIP events on the launch stream, taken in a separate profiled pass so
+           that the event syncs do not perturb the timed steps) vs 8 TB/s
+cpu_baseline = the CPU oracle (a port of the reference's algorithm; the reference
+           itself cannot travel to the GPU box) on a bounded sample, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12
+SIGMAS = (0.002, 0.003, 0.0025, 0.004)
+ALPHAS = (0.3, 0.5, 0.2, 0.4)
+
+# block tensor shapes (rows, cols); 1-D norms have rows = 1 (SURVEY section 8 header)
+LLAMA3_8B_BLOCK = [(4096, 4096), (1024, 4096), (1024, 4096), (4096, 4096),
+                   (14336, 4096), (14336, 4096), (4096, 14336), (1, 4096), (1, 4096)]
+LLAMA3_70B_BLOCK = [(8192, 8192), (1024, 8192), (1024, 8192), (8192, 8192),
+                    (28672, 8192), (28672, 8192), (8192, 28672), (1, 8192), (1, 8192)]
+
+
+def workload_shapes(name: str, blocks: int):
+    if name == "llama3-8b":
+        return LLAMA3_8B_BLOCK * (blocks or 32), "Llama-3-8B block tensors (9 per block x %d blocks)" % (blocks or 32)
+    if name == "llama3-70b-slice":
+        return LLAMA3_70B_BLOCK * (blocks or 10), "Llama-3-70B block tensors, this rank's 1/8 slice (9 per block x %d blocks)" % (blocks or 10)
+    if name == "8192sq":
+        return [(8192, 8192)] * (blocks or 4), "synthetic [8192x8192] tensors x %d" % (blocks or 4)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def alg_bytes_per_elem(k: int) -> int:
+    """B_alg = 60n (K=2), 122n (K=3), 182n (K=4)."""
+    return {1: 8, 2: 60, 3: 122, 4: 182}.get(k, 60 * (k - 1) + 2 * (k - 2))
+
+
+# algorithmic HBM bytes of ONE launch of each kernel on a tensor of n elements
+# (SURVEY 8(d) phase table: P1 = F1, P2 = F2, P3/P6 = select_hist, P4 = reduce,
+#  P5 = blend, P7 = I1, P8 = I2)
+KERNEL_ALG_BYTES = {
+    "f1_rows_fwd": 14.0,     # read 3 bf16 tensors (6n) + write two half-spectra (8n)
+    "f2_cols_fwd": 14.0,     # read 8n + write Re a, Im a, Re b (6n)
+    "i1_cols_inv": 8.0,      # read Re R + Im a (4n) + write 4n
+    "i2_rows_inv": 8.0,      # read 4n + base 2n + write bf16 2n
+    "blend": 6.0,
+    "slerp_reduce": 4.0,
+    "select_hist": 3.0,      # 4n on (Re a, Re b), 2n on Re R: two launches of each per pair
+    "combine": 6.0,
+}
+
+
+def make_inputs(shapes, k, device, seed, shared_base=None):
+    """bf16 base + k finetunes per tensor, generated on the GPU."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    layers = []
+    for i, (r, c) in enumerate(shapes):
+        shape = (c,) if r == 1 else (r, c)
+        if shared_base is not None:
+            base = shared_base[i]
+        else:
+            base = (torch.randn(shape, generator=g, device=device) * 0.02).to(torch.bfloat16)
+        fts = [(base.float() + torch.randn(shape, generator=g, device=device) * SIGMAS[j % 4]).to(torch.bfloat16)
+               for j in range(k)]
+        layers.append((base, fts))
+    return layers
+
+
+def run_step(engine, layers, k):
+    outs = 0
+    for base, fts in layers:
+        out, rep = engine.merge_layer(fts, [base] * k, ALPHAS[:k], base)
+        outs += out.numel()
+    return outs
+
+
+def cpu_baseline(k: int):
+    """The CPU oracle on a bounded sample of the same workload (one 4096 x 4096
+    block tensor, K as benchmarked): about 10-30 s of host work."""
+    from oracle import spectral_oracle as so
+    rows = cols = 4096
+    base, fts = so.synthetic_layer(rows, cols, k, seed=1000)
+    torch.set_num_threads(os.cpu_count() or 1)
+    t0 = time.time()
+    so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base)
+    dt = time.time() - t0
+    return {"value": 2.0 * rows * cols / dt / 1e9, "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle.merge_layer on one synthetic [{rows}x{cols}] bf16 tensor, K={k} ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="llama3-8b")
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from shardmerge_amd.engine import get_engine
+    engine = get_engine(device)
+
+    shapes, desc = workload_shapes(args.workload, args.blocks)
+    k = args.k
+    # stage inputs: rank 0 owns the shared base; ONE RCCL broadcast distributes it
+    bcast_ms = None
+    shared = None
+    if world > 1:
+        g = torch.Generator(device=device).manual_seed(1000)
+        total = sum(r * c for r, c in shapes)
+        flat = torch.empty(total, dtype=torch.bfloat16, device=device)
+        if rank == 0:
+            flat.copy_((torch.randn(total, generator=g, device=device) * 0.02).to(torch.bfloat16))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.time()
+        dist.broadcast(flat, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.time() - t0) * 1e3
+        shared, off = [], 0
+        for r, c in shapes:
+            shared.append(flat[off:off + r * c].view((c,) if r == 1 else (r, c)))
+            off += r * c
+    layers = make_inputs(shapes, k, device, seed=1000 + 17 * rank, shared_base=shared)
+    n_elems = sum(r * c for r, c in shapes)
+
+    for _ in range(args.warmup):
+        run_step(engine, layers, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        run_step(engine, layers, k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.time() - t0
+    if dist:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out_bytes = 2.0 * n_elems * args.steps * world
+    value = out_bytes / dt / 1e9
+    result = {
+        "metric": "merged-weight GB/s per GPU + % HBM roofline, Llama-3-70B 3-way FFT merge",
+        "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{desc}, K={k} finetunes, bf16 in/out, resident in HBM", "tensors_per_step": len(shapes),
+                   "params_per_step_per_gpu": n_elems, "k": k, "parallelism": f"tensor-partition x{world} (no data-path collective)"},
+        "per_gpu_GBps": value / world,
+        "pipeline_hbm_frac": alg_bytes_per_elem(k) * n_elems * args.steps / dt / HBM_PEAK,
+        "base_broadcast_ms": bcast_ms,
+    }
+
+    if rank == 0 and not args.no_profile:
+        engine.ctx.profile(True)
+        engine.ctx.profile_reset()
+        run_step(engine, layers, k)
+        torch.cuda.synchronize()
+        table = engine.ctx.profile_table()
+        engine.ctx.profile(False)
+        tot_ms = sum(ms for _, ms in table.values())
+        kern = {name: {"launches": n, "total_ms": ms, "share": ms / tot_ms if tot_ms else 0} for name, (n, ms) in table.items()}
+        dom = max(table.items(), key=lambda kv: kv[1][1])[0]
+        n_fft = sum(r * c for r, c in shapes if True)
+        # launches of the dominant kernel cover every tensor once per pair merge (K-1 pairs)
+        per_elem = KERNEL_ALG_BYTES.get(dom, 0.0)
+        pairs = max(k - 1, 1)
+        launches_per_tensor = {"select_hist": 4}.get(dom, 1)
+        alg = per_elem * n_fft * pairs * launches_per_tensor
+        dom_s = table[dom][1] / 1e3
+        traffic = None
+        tf = REPO / "profiles" / "traffic_latest.json"
+        if tf.exists():
+            try:
+                traffic = json.load(open(tf)).get(dom)
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg / dom_s / 1e9, "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": alg / dom_s / HBM_PEAK, "traffic": traffic,
+                              "alg_bytes_per_elem": per_elem, "avg_launch_ms": table[dom][1] / table[dom][0]}
+        result["kernels"] = kern
+        result["device_ms_profiled_step"] = tot_ms
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(k)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,15 +139,43 @@ def run_ref_layer(case, tmp):
     return asyncio.run(go())
 
 
+class fp64_fft:
+    """Context: the reference's torch.fft calls evaluated in float64 and rounded back.
+    Used to measure how much the REFERENCE's own output moves under a (more
+    accurate) FFT: its reproducibility floor (see oracle/chaos_probe.py)."""
+    NAMES = ("fft", "fftn", "ifft", "ifftn")
+
+    def __enter__(self):
+        self.orig = {n: getattr(torch.fft, n) for n in self.NAMES}
+
+        def wrap(f):
+            def g(x, *a, **k):
+                x = x.to(torch.complex128) if x.is_complex() else x.to(torch.float64)
+                return f(x, *a, **k).to(torch.complex64)
+            return g
+        for n in self.NAMES:
+            setattr(torch.fft, n, wrap(self.orig[n]))
+
+    def __exit__(self, *exc):
+        for n in self.NAMES:
+            setattr(torch.fft, n, self.orig[n])
+
+
 def gen_layers(manifest):
     store = {}
+    floors = {}
     with tempfile.TemporaryDirectory() as tmp:
         for case in gi.LAYER_CASES:
             out = run_ref_layer(case, tmp)
             store[case["id"]] = out.contiguous().clone()
             tensors, _, _, _ = gi.layer_inputs(case)
             manifest["inputs"][case["id"]] = sum((gi.checksum(v) for v in tensors.values()), [])
+            with fp64_fft():
+                out64 = run_ref_layer(case, tmp)
+            d = (out.double() - out64.double()).norm() / out.double().norm()
+            floors[case["id"]] = float(d)
     save_file(store, str(OUT / "g7_layer.safetensors"))
+    manifest["layer_self_floor"] = floors
 
 
 def gen_cli(manifest):

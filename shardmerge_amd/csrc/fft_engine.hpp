@@ -264,55 +264,113 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
     }
 }
 
+// component selector with a compile-time index: keeps every register-array
+// access statically indexed (a runtime `comp ? xi : xr` pointer sends the arrays
+// to scratch memory).
+template <int COMP, class S> SM_HD float* comp_of(S& s) { if constexpr (COMP == 0) return s.xr; else return s.xi; }
+
+// ---- plans -------------------------------------------------------------------
+// DynPlan: length, thread count and radix list are run-time values (any
+// supported length; the radix of each pass is dispatched with a switch).
+// SPlan<N, T, R...>: everything is a compile-time constant, the passes are
+// unrolled into straight-line code and all index arithmetic folds.  The hot
+// lengths (powers of two up to 16384, 7*2^11, 7*2^12) get an SPlan instantiation.
+struct DynPlan { static constexpr bool is_static = false; };
+template <int N_, int T_, int... RS>
+struct SPlan {
+    static constexpr bool is_static = true;
+    static constexpr int N = N_, T = T_, npass = (int)sizeof...(RS);
+    static constexpr int radix(int i) { constexpr int r[] = {RS...}; return r[i]; }
+    static constexpr int ns(int p) { int v = 1; for (int i = 0; i < p; ++i) v *= radix(i); return v; }
+    static constexpr int lds_floats = ((N_ + (N_ >> 5) + 1 + 31) / 32) * 32;
+    static_assert(ns(npass) == N_, "radices must multiply to N");
+};
+template <class P> SM_HD int plan_N(const FftPlanDev& pl) { if constexpr (P::is_static) return P::N; else return pl.N; }
+template <class P> SM_HD int plan_T(const FftPlanDev& pl) { if constexpr (P::is_static) return P::T; else return pl.T; }
+template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::is_static) return P::lds_floats; else return pl.lds_floats; }
+
 // Run a whole transform for every group of a work-group.
-//   nat_scatter(tid, state, comp): write the loaded, natural-order values of
-//        component comp (0 = re, 1 = im) into LDS (element n of group g at
-//        lds + g*lds_floats + lpad(n)).
-//   fin_gather(tid, state, comp): read from LDS (natural order X[k]) what the
+//   nat_scatter(tid, state, comp_c): write the loaded, natural-order values of
+//        component comp (0 = re, 1 = im; passed as std::integral_constant) into
+//        LDS (element n of group g at lds + g*lds_floats + lpad(n)).
+//   fin_gather(tid, state, comp_c): read from LDS (natural order X[k]) what the
 //        storer needs of component comp.
 // State must expose float xr[EREG], xi[EREG].
-template <class Ex, class StT, class NatScatter, class FinGather>
+template <class P, class Ex, class StT, class NatScatter, class FinGather>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
     using S = typename StT::value_type;
-    const int N = pl.N, T = pl.T;
-    // natural -> first pass layout, one component at a time
-    for (int comp = 0; comp < 2; ++comp) {
-        ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp); });
-        ex.sync();
-        ex.each(st, [&](int tid, S& s) {
-            float* x = comp ? s.xi : s.xr;
-            const float* l = lds + (tid / T) * pl.lds_floats;
-            SM_RADIX_SWITCH(pl.radix[0], pass_gather<RX>(x, l, N, T, tid % T));
-        });
-        ex.sync();
-    }
-    int Ns = 1;
-    for (int p = 0; p < pl.npass; ++p) {
-        const int r = pl.radix[p];
-        ex.each(st, [&](int tid, S& s) {
-            SM_RADIX_SWITCH(r, pass_compute<RX>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw));
-        });
-        const bool last = (p + 1 == pl.npass);
-        for (int comp = 0; comp < 2; ++comp) {
+    const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
+    if constexpr (P::is_static) {
+        static_for<0, 2>([&](auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
+            ex.sync();
             ex.each(st, [&](int tid, S& s) {
-                const float* x = comp ? s.xi : s.xr;
-                float* l = lds + (tid / T) * pl.lds_floats;
-                SM_RADIX_SWITCH(r, pass_scatter<RX>(x, l, N, Ns, T, tid % T));
+                pass_gather<P::radix(0)>(comp_of<comp>(s), lds + (tid / T) * LF, N, T, tid % T);
             });
             ex.sync();
-            if (!last) {
-                const int rn = pl.radix[p + 1];
+        });
+        static_for<0, P::npass>([&](auto p_c) {
+            constexpr int p = decltype(p_c)::value;
+            constexpr int r = P::radix(p);
+            constexpr int Ns = P::ns(p);
+            constexpr bool last = (p + 1 == P::npass);
+            ex.each(st, [&](int tid, S& s) { pass_compute<r>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw); });
+            static_for<0, 2>([&](auto comp_c) {
+                constexpr int comp = decltype(comp_c)::value;
                 ex.each(st, [&](int tid, S& s) {
-                    float* x = comp ? s.xi : s.xr;
-                    const float* l = lds + (tid / T) * pl.lds_floats;
-                    SM_RADIX_SWITCH(rn, pass_gather<RX>(x, l, N, T, tid % T));
+                    pass_scatter<r>(comp_of<comp>(s), lds + (tid / T) * LF, N, Ns, T, tid % T);
                 });
-            } else {
-                ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp); });
-            }
+                ex.sync();
+                if constexpr (!last) {
+                    ex.each(st, [&](int tid, S& s) {
+                        pass_gather<P::radix(last ? p : p + 1)>(comp_of<comp>(s), lds + (tid / T) * LF, N, T, tid % T);
+                    });
+                } else {
+                    ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
+                }
+                ex.sync();
+            });
+        });
+    } else {
+        // natural -> first pass layout, one component at a time
+        static_for<0, 2>([&](auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
             ex.sync();
+            ex.each(st, [&](int tid, S& s) {
+                const float* l = lds + (tid / T) * LF;
+                SM_RADIX_SWITCH(pl.radix[0], pass_gather<RX>(comp_of<comp>(s), l, N, T, tid % T));
+            });
+            ex.sync();
+        });
+        int Ns = 1;
+        for (int p = 0; p < pl.npass; ++p) {
+            const int r = pl.radix[p];
+            ex.each(st, [&](int tid, S& s) {
+                SM_RADIX_SWITCH(r, pass_compute<RX>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw));
+            });
+            const bool last = (p + 1 == pl.npass);
+            static_for<0, 2>([&](auto comp_c) {
+                constexpr int comp = decltype(comp_c)::value;
+                ex.each(st, [&](int tid, S& s) {
+                    float* l = lds + (tid / T) * LF;
+                    SM_RADIX_SWITCH(r, pass_scatter<RX>(comp_of<comp>(s), l, N, Ns, T, tid % T));
+                });
+                ex.sync();
+                if (!last) {
+                    const int rn = pl.radix[p + 1];
+                    ex.each(st, [&](int tid, S& s) {
+                        const float* l = lds + (tid / T) * LF;
+                        SM_RADIX_SWITCH(rn, pass_gather<RX>(comp_of<comp>(s), l, N, T, tid % T));
+                    });
+                } else {
+                    ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
+                }
+                ex.sync();
+            });
+            Ns *= r;
         }
-        Ns *= r;
     }
 }
 

@@ -137,13 +137,14 @@ struct F1Params {
     double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
 };
 
-template <class Ex>
+template <class P, class Ex>
 SM_HD void k_f1(Ex& ex, const F1Params& p) {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
     const FftPlanDev& pl = p.plan;
-    const int T = pl.T, C = p.C;
+    const int T = plan_T<P>(pl), C = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
     const int bid = ex.bid();
 
     ex.each(st, [&](int tid, FftState& s) {
@@ -193,11 +194,12 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         p.partials[2 * (size_t)bid + 1] = tot[1];
     });
 
-    wg_fft(ex, st, pl, lds,
-        [&](int tid, FftState& s, int comp) {          // natural scatter
+    wg_fft<P>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // natural scatter
             const int g = tid / T, t = tid % T;
-            float* l = lds + g * pl.lds_floats;
-            const float* x = comp ? s.xi : s.xr;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
             if (p.vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
@@ -215,10 +217,11 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
                 }
             }
         },
-        [&](int tid, FftState& s, int comp) {          // final gather: pairs (k, C-k)
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // final gather: pairs (k, C-k)
             const int g = tid / T, t = tid % T;
-            const float* l = lds + g * pl.lds_floats;
-            float* o = comp ? s.xi : s.xr;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 2 + 1; ++u) {
                 const int k = t + u * T;
@@ -263,18 +266,19 @@ struct F2Params {
     unsigned long long* hist;               // level-1 histogram (HIST1_BINS) or null
 };
 
-template <class Ex>
+template <class P, class Ex>
 SM_HD void k_f2(Ex& ex, const F2Params& p) {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
     const FftPlanDev& pl = p.plan;
-    const int T = pl.T, R = p.R;
+    const int T = plan_T<P>(pl), R = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
     const int ng = p.nsig;
     const int bid = ex.bid();
     const int k2 = (ng == 2) ? bid : bid / 2;
     const int slot0 = (ng == 2) ? 0 : bid % 2;
-    uint32_t* lhist = (uint32_t*)(lds + ng * pl.lds_floats);
+    uint32_t* lhist = (uint32_t*)(lds + ng * LF);
 
     ex.each(st, [&](int tid, FftState& s) {
         if (ng == 2) {
@@ -300,14 +304,15 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         if (p.hist) for (int b = tid; b < HIST1_BINS; b += ng * T) lhist[b] = 0;
     });
 
-    wg_fft(ex, st, pl, lds,
-        [&](int tid, FftState& s, int comp) {
-            const float* x = comp ? s.xi : s.xr;
+    wg_fft<P>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            const float* x = comp_of<comp>(s);
             if (ng == 2) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 2; ++q) {
                     const int n = tid + q * 2 * T;
-                    if (n < R) { lds[lpad(n)] = x[2 * q]; lds[pl.lds_floats + lpad(n)] = x[2 * q + 1]; }
+                    if (n < R) { lds[lpad(n)] = x[2 * q]; lds[LF + lpad(n)] = x[2 * q + 1]; }
                 }
             } else {
 #pragma unroll
@@ -317,10 +322,11 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                 }
             }
         },
-        [&](int tid, FftState& s, int comp) {
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
-            const float* l = lds + g * pl.lds_floats;
-            float* o = comp ? s.xi : s.xr;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 4; ++u) {
 #pragma unroll
@@ -394,13 +400,14 @@ struct I1Params {
     int pitchG;
 };
 
-template <int S, class Ex>
+template <class P, int S, class Ex>
 SM_HD void k_i1(Ex& ex, const I1Params& p) {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
     const FftPlanDev& pl = p.plan;
-    const int T = pl.T, R = p.R;
+    const int T = plan_T<P>(pl), R = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
     const int bid = ex.bid();
     const float thr = p.cull_thr ? *p.cull_thr : 0.f;
 
@@ -435,11 +442,12 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         }
     });
 
-    wg_fft(ex, st, pl, lds,
-        [&](int tid, FftState& s, int comp) {
+    wg_fft<P>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
-            float* l = lds + g * pl.lds_floats;
-            const float* x = comp ? s.xi : s.xr;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 4; ++u) {
 #pragma unroll
@@ -449,15 +457,16 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
                 }
             }
         },
-        [&](int tid, FftState& s, int comp) {
-            float* o = comp ? s.xi : s.xr;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            float* o = comp_of<comp>(s);
             // thread handles rows r = tid + q*(S*T); needs every group's value
 #pragma unroll
             for (int q = 0; q < EMAX / S; ++q) {
                 const int r = tid + q * S * T;
                 if (r < R) {
 #pragma unroll
-                    for (int g = 0; g < S; ++g) o[q * S + g] = lds[g * pl.lds_floats + lpad(r)];
+                    for (int g = 0; g < S; ++g) o[q * S + g] = lds[g * LF + lpad(r)];
                 }
             }
         });
@@ -521,13 +530,14 @@ SM_HD void i2_finish(const I2Params& p, float v, size_t off, uint32_t& nan1, uin
     outv = v;
 }
 
-template <class Ex>
+template <class P, class Ex>
 SM_HD void k_i2(Ex& ex, const I2Params& p) {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
     const FftPlanDev& pl = p.plan;
-    const int T = pl.T, C = p.C;
+    const int T = plan_T<P>(pl), C = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
     const int bid = ex.bid();
 
     ex.each(st, [&](int tid, FftState& s) {
@@ -552,11 +562,12 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         }
     });
 
-    wg_fft(ex, st, pl, lds,
-        [&](int tid, FftState& s, int comp) {
+    wg_fft<P>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
-            float* l = lds + g * pl.lds_floats;
-            const float* x = comp ? s.xi : s.xr;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 2 + 1; ++u) {
                 const int k = t + u * T;
@@ -566,10 +577,11 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                 }
             }
         },
-        [&](int tid, FftState& s, int comp) {
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
-            const float* l = lds + g * pl.lds_floats;
-            float* o = comp ? s.xi : s.xr;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
             if (p.vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
@@ -593,10 +605,11 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         const int r0 = 2 * (bid * p.nb + g);
         uint32_t nan1 = 0, inf1 = 0, nan2 = 0, inf2 = 0;
         // after the swap trick the true (re, im) = (xi, xr): row r0 = re, row r0+1 = im
-        for (int h = 0; h < 2; ++h) {
+        static_for<0, 2>([&](auto h_c) {
+            constexpr int h = decltype(h_c)::value;
             const int row = r0 + h;
-            if (row >= p.R) continue;
-            const float* x = h ? s.xr : s.xi;
+            if (row >= p.R) return;
+            const float* x = comp_of<1 - h>(s);
             if (p.vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
@@ -648,7 +661,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                     }
                 }
             }
-        }
+        });
         if (nan1) ex.global_atomic_add_u32(&p.flags[0], nan1);
         if (inf1) ex.global_atomic_or_u32(&p.flags[1], 1u);
         if (nan2) ex.global_atomic_add_u32(&p.flags[2], nan2);

@@ -23,11 +23,37 @@ namespace smhip {
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
-SM_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1(ex, p))
-SM_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", k_f2(ex, p))
-SM_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv_s1", k_i1<1>(ex, p))
-SM_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv_s2", k_i1<2>(ex, p))
-SM_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2(ex, p))
+// the four transform kernels exist once per static plan plus once for DynPlan
+#define SM_FFT_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                  \
+    template <class P> struct Tag {                                                  \
+        using Params = ParamsT;                                                      \
+        static const char* name() { return NAME; }                                   \
+        template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
+    };
+SM_FFT_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1<P>(ex, p))
+SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", k_f2<P>(ex, p))
+SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)))
+SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, 2>(ex, p)))
+SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p))
+
+// lengths that get straight-line kernels; must agree with plan_shape() below
+// (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
+#define SM_STATIC_PLANS(X)          \
+    X(SPlan<1024, 64, 32, 32>)      \
+    X(SPlan<2048, 64, 16, 16, 8>)   \
+    X(SPlan<4096, 128, 16, 16, 16>) \
+    X(SPlan<8192, 256, 32, 16, 16>) \
+    X(SPlan<16384, 512, 32, 32, 16>)\
+    X(SPlan<14336, 512, 16, 16, 8, 7>) \
+    X(SPlan<28672, 1024, 16, 16, 16, 7>)
+
+template <class PL>
+inline bool plan_matches(const FftPlanDev& pl) {
+    if (pl.N != PL::N || pl.T != PL::T || pl.npass != PL::npass || pl.lds_floats != PL::lds_floats) return false;
+    for (int i = 0; i < PL::npass; ++i)
+        if (pl.radix[i] != PL::radix(i)) return false;
+    return true;
+}
 SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
@@ -208,6 +234,20 @@ class Pipeline {
     float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
     enum { P_REA = 0, P_IMA = 1, P_REB = 2, P_RER = 3 };
 
+    // launch the static-plan instantiation of a transform kernel when one matches
+    template <template <class> class KT, class Params>
+    void launch_fft(const FftPlanDev& pl, int grid, int block, size_t lds, const Params& p) {
+        bool done = false;
+#define SM_TRY_PLAN(...)                                                     \
+        if (!done && plan_matches<__VA_ARGS__>(pl)) {                        \
+            be.template launch<KT<__VA_ARGS__>>(grid, block, lds, p, stream);\
+            done = true;                                                     \
+        }
+        SM_STATIC_PLANS(SM_TRY_PLAN)
+#undef SM_TRY_PLAN
+        if (!done) be.template launch<KT<DynPlan>>(grid, block, lds, p, stream);
+    }
+
     // ---- stages ------------------------------------------------------------------
     static int stream_grid(size_t units, int block, int chunks) {
         const size_t per = (size_t)block * chunks;
@@ -230,7 +270,7 @@ class Pipeline {
         const int grid = (g.R + p.nb - 1) / p.nb;
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
-        be.template launch<KF1>(grid, p.nb * p.plan.T, lds, p, stream);
+        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p);
         grid_out = grid;
         return SMHIP_OK;
     }
@@ -253,7 +293,7 @@ class Pipeline {
         p.hist = hist ? d_hist() : nullptr;
         const int grid = p.Cb * (p.nsig == 2 ? 1 : 2);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nsig * p.plan.lds_floats + HIST1_BINS) * 4;
-        be.template launch<KF2>(grid, p.nsig * p.plan.T, lds, p, stream);
+        launch_fft<KF2>(p.plan, grid, p.nsig * p.plan.T, lds, p);
         return SMHIP_OK;
     }
 
@@ -312,8 +352,8 @@ class Pipeline {
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
         const int grid1 = (Cb + a.s - 1) / a.s;
-        if (a.s == 2) be.template launch<KI1x2>(grid1, 2 * a.plan.T, lds1, a, stream);
-        else be.template launch<KI1x1>(grid1, a.plan.T, lds1, a, stream);
+        if (a.s == 2) launch_fft<KI1x2>(a.plan, grid1, 2 * a.plan.T, lds1, a);
+        else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
 
         I2Params b;
         if ((rc = get_plan(g.C, b.plan))) return rc;
@@ -327,7 +367,7 @@ class Pipeline {
         const int pairs = (g.R + 1) / 2;
         const int grid2 = (pairs + b.nb - 1) / b.nb;
         const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
-        be.template launch<KI2>(grid2, b.nb * b.plan.T, lds2, b, stream);
+        launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b);
         return SMHIP_OK;
     }
 

@@ -8,67 +8,17 @@
 #include <string>
 #include <vector>
 
-#include "sm_pipeline.hpp"
+#include "smhip_device.hpp"
 
 #define SM_VERSION_STRING "shardmerge-hip 0.1 (gfx950)"
 
 namespace smhip {
 
-struct DeviceExec {
-    template <class S> struct State { using value_type = S; S s; };
-    __device__ __forceinline__ int bid() const { return blockIdx.x; }
-    __device__ __forceinline__ int nthreads() const { return blockDim.x; }
-    __device__ __forceinline__ float* lds() {
-        extern __shared__ __attribute__((aligned(16))) float sm_dyn_lds[];
-        return sm_dyn_lds;
-    }
-    template <class S> __device__ __forceinline__ void init(State<S>&) {}
-    template <class S, class F> __device__ __forceinline__ void each(State<S>& st, F&& f) { f((int)threadIdx.x, st.s); }
-    __device__ __forceinline__ void sync() { __syncthreads(); }
-    __device__ __forceinline__ void lds_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
-    __device__ __forceinline__ void global_atomic_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
-    __device__ __forceinline__ void global_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
-    __device__ __forceinline__ void global_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-
-    // sum NV doubles (State::red) over the work-group; f(total) runs on thread 0.
-    // Uses the first LDS_SCRATCH_FLOATS of LDS; ends with a barrier.
-    template <int NV, class S, class F>
-    __device__ __forceinline__ void block_sum(State<S>& st, F&& f) {
-        double v[NV];
-#pragma unroll
-        for (int q = 0; q < NV; ++q) v[q] = st.s.red[q];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) v[q] += __shfl_down(v[q], off, 64);
-        }
-        double* scratch = (double*)lds();
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int nw = (blockDim.x + 63) >> 6;
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) scratch[wave * NV + q] = v[q];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot[NV];
-#pragma unroll
-            for (int q = 0; q < NV; ++q) tot[q] = 0.0;
-            for (int w = 0; w < nw; ++w) {
-#pragma unroll
-                for (int q = 0; q < NV; ++q) tot[q] += scratch[w * NV + q];
-            }
-            f((const double*)tot);
-        }
-        __syncthreads();
-    }
-};
-
-template <class K>
-__global__ void __launch_bounds__(1024) sm_kernel(const typename K::Params p) {
-    DeviceExec ex;
-    K::run(ex, p);
-}
+#define SM_DECL_EXTERN(...) extern template __global__ void sm_kernel<__VA_ARGS__>(const typename __VA_ARGS__::Params);
+#define SM_DECL_PLAN(...) SM_FFT_KERNELS_OF(SM_DECL_EXTERN, __VA_ARGS__)
+SM_STATIC_PLANS(SM_DECL_PLAN)
+#undef SM_DECL_PLAN
+#undef SM_DECL_EXTERN
 
 struct HipBackend {
     int device;
