@@ -32,6 +32,38 @@ import torch
 
 CPU = "cpu"
 
+# ---------------------------------------------------------------------------
+# L2 norms.  The reference takes every norm with torch.norm / Tensor.norm /
+# F.normalize on CPU fp32 tensors.  ATen's CPU kernel for that accumulates x*x
+# serially in 8 fp32 vector lanes (AVX2), which loses low-order bits once the
+# running sum is large: -1e-5 relative at 1M elements, -7e-4 at 16M, -5e-3 at
+# 67M (oracle/norm_bias_probe.py).  NORM_MODE = "torch" restates the reference
+# as it is (and is what the goldens pin); "exact" takes the same norms with an
+# accurate sum - what the reference's own device="cuda" mode and the HIP path
+# compute - so that parity tests at >= 1M elements can separate that artefact
+# from everything else.
+# ---------------------------------------------------------------------------
+NORM_MODE = "torch"
+
+
+class exact_norms:
+    """Context manager: evaluate the oracle with accurate L2 norms."""
+
+    def __enter__(self):
+        global NORM_MODE
+        self._old = NORM_MODE
+        NORM_MODE = "exact"
+
+    def __exit__(self, *exc):
+        global NORM_MODE
+        NORM_MODE = self._old
+
+
+def l2norm(x: torch.Tensor) -> torch.Tensor:
+    if NORM_MODE == "exact":
+        return x.double().pow(2).sum().sqrt().to(torch.float32)
+    return x.norm()
+
 
 # --------------------------------------------------------------------------
 # A6 - slerp on the gathered (1-D, masked) real parts
@@ -43,10 +75,14 @@ def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float) -> torch.Tensor:
     the *un-normalised* vectors, ``v1 - c*v0`` is normalised to unit length and
     the result is ``v0*cos(theta) + unit*sin(theta)``.
     """
-    c = torch.sum(v0 * v1) / (v0.norm() * v1.norm())
+    c = torch.sum(v0 * v1) / (l2norm(v0) * l2norm(v1))
     c = torch.clamp(c, -1.0, 1.0)
     theta = torch.acos(c) * t
-    rel = torch.nn.functional.normalize(v1 - v0 * c, dim=-1)
+    rel = v1 - v0 * c
+    if NORM_MODE == "exact":
+        rel = rel / torch.clamp(l2norm(rel), min=1e-12)
+    else:
+        rel = torch.nn.functional.normalize(rel, dim=-1)
     return v0 * torch.cos(theta) + rel * torch.sin(theta)
 
 
@@ -70,7 +106,7 @@ def ifft_transform(spec: torch.Tensor) -> torch.Tensor:
 
 def normalize_tensor(x: torch.Tensor) -> Tuple[torch.Tensor, float]:
     """reference shard/tensor/functions.py:75-88: x/||x||, untouched if 0."""
-    nrm = x.norm().item()
+    nrm = l2norm(x).item()
     if nrm == 0:
         return x, nrm
     return x / nrm, nrm
@@ -321,7 +357,7 @@ def merge_layer(
     weights: List[float] = []
     for i in range(k):
         delta = (finetunes[i].to(torch.float32) - bases[i].to(torch.float32)).detach() * 1
-        layer_norms.append(torch.norm(delta))
+        layer_norms.append(l2norm(delta))
         store[names[i]] = delta
         stack.append(names[i])
         weights.append(alphas[i])
@@ -351,7 +387,7 @@ def merge_layer(
             a_name, b_name = stack[x], stack[y]
             a_w, b_w = weights[x], weights[y]
             a, b = store[a_name], store[b_name]
-            na, nb = torch.norm(a).item(), torch.norm(b).item()
+            na, nb = l2norm(a).item(), l2norm(b).item()
             if abs(na) < abs(nb):
                 a, b = b, a
                 a_name, b_name = b_name, a_name

@@ -52,29 +52,42 @@ def test_layer(engine, golden, case):
 
 
 # ---- mid sizes against the oracle (seconds of CPU work) -----------------------------
+# From ~1M elements on, torch's CPU norm kernel (8-lane serial fp32 accumulation)
+# is visibly biased (oracle/norm_bias_probe.py); the reference's output depends on
+# the a/b norm RATIO through hard |r0| > |r1| decisions, so its bias moves the
+# reference itself by ~3e-3 (merged delta) at 1024^2.  The HIP path takes exact L2
+# norms (as the reference's device="cuda" mode does): we therefore check tightly
+# against the oracle evaluated with exact norms, and loosely against the oracle as
+# the reference is (torch norms).
 @pytest.mark.parametrize("shape", [(1024, 1024), (2048, 512), (448, 1024), (1024, 14336 // 8), (1, 8192)],
                          ids=lambda s: f"{s[0]}x{s[1]}")
 def test_layer_k2_vs_oracle(engine, shape):
     rows, cols = shape
     base, fts = so.synthetic_layer(rows, cols, 2, seed=4000 + rows)
-    tr = so.LayerTrace()
+    tr, trx = so.LayerTrace(), so.LayerTrace()
     ref = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr)
+    with so.exact_norms():
+        refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
     out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
     assert rep.branches == tr.branches == ["slerp"]
-    d_total, d_resid = pc.spectral_residual(delta.cpu(), tr.merged_delta)
-    assert d_resid < 2e-5
+    assert abs(rep.target_norm - trx.target_norm) <= 2e-6 * trx.target_norm
+    d_total, d_resid = pc.spectral_residual(delta.cpu(), trx.merged_delta)
+    assert d_resid < 2e-5, f"vs exact-norm oracle beyond the tie bins: {d_resid:.2e}"
     assert d_total < 8.0 / math.sqrt(rows * cols) + 1e-6
     # BASELINE tolerance: 1e-3 relative on the bf16 output
-    assert so.rel_err(out.cpu().float(), ref.float()) < 1e-3
-    # and the stricter one on the fp32 merged delta once n is large enough
+    assert so.rel_err(out.cpu().float(), refx.float()) < 1e-3
     if rows * cols >= 1 << 20:
-        assert d_total < 1e-3
+        assert d_total < 1e-3            # the stricter delta-level bar of SURVEY 8(d)
+    # against the reference as it is: bounded by what its own norm artefact does to it
+    shift = so.rel_err(ref.float(), refx.float())
+    assert so.rel_err(out.cpu().float(), ref.float()) < 1e-3 + 1.5 * shift
 
 
 def test_layer_k3_vs_oracle(engine):
     base, fts = so.synthetic_layer(1024, 1024, 3, seed=5000)
     tr = so.LayerTrace()
-    ref = so.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, trace=tr)
+    with so.exact_norms():
+        ref = so.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, trace=tr)
     out, rep = engine.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base)
     assert rep.branches == tr.branches
     # round 2 of the reference decides on rounding noise (oracle/chaos_probe.py): its own
