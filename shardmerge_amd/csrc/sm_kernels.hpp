@@ -230,6 +230,9 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
                     const float v1 = l[lpad(k)], v2 = l[lpad(k2)];
                     if (comp == 0) { o[2 * u] = 0.5f * (v1 + v2); o[2 * u + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
                     else           { o[2 * u] = 0.5f * (v1 - v2); o[2 * u + 1] = 0.5f * (v1 + v2); }   // A.im, B.re
+                    // an absent second signal is EXACTLY zero (its sign class matters: sign(0) = 0);
+                    // the split above would leave rounding noise of random sign there
+                    if (!p.b.x) o[2 * u + 1] = 0.f;
                 }
             }
         });
@@ -876,19 +879,24 @@ struct SlerpConstParams {
     BlendConsts* out;
 };
 
-// single thread: sum the partials in a fixed order and derive the constants
-// (reference functions.py:36-43 on the gathered slerp-class vectors)
+// one work-group: sum the partials (fixed order per thread, then the block
+// reduction) and derive the constants (reference functions.py:36-43 on the
+// gathered slerp-class vectors)
 template <class Ex>
 SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
-    ex.each(st, [&](int tid, EmptyState&) {
-        if (tid != 0) return;
-        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
-        for (int i = 0; i < p.nparts; ++i) {
-            s00 += p.partials[4 * i]; s01 += p.partials[4 * i + 1];
-            s11 += p.partials[4 * i + 2]; cnt += p.partials[4 * i + 3];
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int i = tid; i < p.nparts; i += nt) {
+            a0 += p.partials[4 * i]; a1 += p.partials[4 * i + 1];
+            a2 += p.partials[4 * i + 2]; a3 += p.partials[4 * i + 3];
         }
+        s.red[0] = a0; s.red[1] = a1; s.red[2] = a2; s.red[3] = a3;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        const double s00 = tot[0], s01 = tot[1], s11 = tot[2], cnt = tot[3];
         BlendConsts c;
         c.thr = p.thr ? *p.thr : 0.f;
         c.s00 = s00; c.s01 = s01; c.s11 = s11; c.n_slerp = (unsigned long long)cnt;
@@ -905,6 +913,21 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
         c.pad[0] = c.pad[1] = c.pad[2] = 0.f;
         *p.out = c;
     });
+}
+
+// sum [n][2] double partials into out[2] (norm^2 of the two signals of F1 / combine)
+struct SumPartialsParams { const double* partials; int nparts; double* out; };
+template <class Ex>
+SM_HD void k_sum_partials(Ex& ex, const SumPartialsParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double a0 = 0, a1 = 0;
+        for (int i = tid; i < p.nparts; i += nt) { a0 += p.partials[2 * i]; a1 += p.partials[2 * i + 1]; }
+        s.red[0] = a0; s.red[1] = a1;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) { p.out[0] = tot[0]; p.out[1] = tot[1]; });
 }
 
 enum { BLEND_SLERP = 0, BLEND_ARITH = 1 };

@@ -58,6 +58,7 @@ SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
 SM_KERNEL_TAG(KSlerpConsts, SlerpConstParams, "slerp_consts", k_slerp_consts(ex, p))
+SM_KERNEL_TAG(KSumPartials, SumPartialsParams, "sum_partials", k_sum_partials(ex, p))
 SM_KERNEL_TAG(KBlend, BlendParams, "blend", k_blend(ex, p))
 SM_KERNEL_TAG(KCombine, CombineParams, "combine", k_combine(ex, p))
 SM_KERNEL_TAG(KExpand, ExpandParams, "expand_full", k_expand(ex, p))
@@ -222,7 +223,8 @@ class Pipeline {
     static constexpr size_t OFF_CONSTS = OFF_SEL + 2 * sizeof(SelState);   // BlendConsts
     static constexpr size_t OFF_THR = OFF_CONSTS + 256;                    // float thr[4]
     static constexpr size_t OFF_FLAGS = OFF_THR + 64;                      // u32[8]
-    static constexpr size_t OFF_PART = OFF_FLAGS + 64;                     // double partials
+    static constexpr size_t OFF_NORM2 = OFF_FLAGS + 64;                    // double[2]
+    static constexpr size_t OFF_PART = OFF_NORM2 + 64;                     // double partials
     static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
     static constexpr size_t SMALL_BYTES = OFF_PART + PART_DOUBLES * 8;
     unsigned long long* d_hist() { return (unsigned long long*)((char*)small_.p + OFF_HIST); }
@@ -230,6 +232,7 @@ class Pipeline {
     BlendConsts* d_consts() { return (BlendConsts*)((char*)small_.p + OFF_CONSTS); }
     float* d_thr(int i) { return (float*)((char*)small_.p + OFF_THR) + i; }
     uint32_t* d_flags() { return (uint32_t*)((char*)small_.p + OFF_FLAGS); }
+    double* d_norm2() { return (double*)((char*)small_.p + OFF_NORM2); }
     double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
     float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
     enum { P_REA = 0, P_IMA = 1, P_REB = 2, P_RER = 3 };
@@ -275,11 +278,12 @@ class Pipeline {
         return SMHIP_OK;
     }
     void read_norms(int grid, double& na, double& nb) {
-        host_part_.resize((size_t)grid * 2);
-        be.d2h(host_part_.data(), d_part(), sizeof(double) * grid * 2, stream);
-        double sa = 0, sb = 0;
-        for (int i = 0; i < grid; ++i) { sa += host_part_[2 * i]; sb += host_part_[2 * i + 1]; }
-        na = std::sqrt(sa); nb = std::sqrt(sb);
+        SumPartialsParams sp;
+        sp.partials = d_part(); sp.nparts = grid; sp.out = d_norm2();
+        be.template launch<KSumPartials>(1, 256, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        double two[2];
+        be.d2h(two, d_norm2(), sizeof two, stream);
+        na = std::sqrt(two[0]); nb = std::sqrt(two[1]);
     }
 
     int run_f2(const Geo& g, float scale0, float scale1, int swap, bool hist) {
@@ -339,7 +343,7 @@ class Pipeline {
         be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
         SlerpConstParams c;
         c.partials = d_part(); c.nparts = grid; c.thr = r.thr; c.t = t; c.out = d_consts();
-        be.template launch<KSlerpConsts>(1, 64, LDS_SCRATCH_FLOATS * 4, c, stream);
+        be.template launch<KSlerpConsts>(1, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
     }
 
     int run_inverse(const Geo& g, const float* reR, const float* imA, const float* cull_thr, const PairOut& o) {
@@ -529,12 +533,13 @@ class Pipeline {
             grid = -1;
         }
         float pre = 1.f;
+        if (nb == 0) { b.x = nullptr; b.base = nullptr; }     // exactly zero: F1 writes exact zeros
         if (nb > 0 && na > 0 && (nb < na * 0.25 || nb > na * 4.0)) {
             int e;
             std::frexp(na / nb, &e);
             pre = std::ldexp(1.f, e - 1);
         }
-        if (pre != 1.f || grid < 0) {
+        if (pre != 1.f || grid < 0 || nb == 0) {
             b.prescale = b_in.prescale * pre;
             if ((rc = run_f1(g, a, b, grid))) return rc;
         }
