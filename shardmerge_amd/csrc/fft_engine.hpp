@@ -210,16 +210,34 @@ template <> struct Dft<13> { static SM_HD void run(float* re, float* im) { DftOd
 // writes out[(j - j mod Ns)*R + (j mod Ns) + i*Ns].  Thread t owns butterflies
 // j = t + m*T; their values sit in x[m*R + i].
 
+// lpad(b + c) = lpad(b) + lpad(c) whenever b is a multiple of 32, so every LDS
+// address below is "one thread-dependent base + a compile-time constant": with a
+// static plan the constants fold into the ds_read/ds_write immediate offsets
+// (no per-element address registers, no per-element address arithmetic).
+
 template <int R>
 SM_HD void pass_gather(float* x, const float* lds, int N, int T, int t) {
     constexpr int MB = EMAX / R;
     const int nb = N / R;
+    if ((nb & 31) == 0) {
+        const int step = nb + (nb >> 5);               // lpad(i*nb) = i*step
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        const int j = t + m * T;
-        if (j < nb) {
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+                const float* b = lds + lpad(j);
 #pragma unroll
-            for (int i = 0; i < R; ++i) x[m * R + i] = lds[lpad(j + i * nb)];
+                for (int i = 0; i < R; ++i) x[m * R + i] = b[i * step];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) x[m * R + i] = lds[lpad(j + i * nb)];
+            }
         }
     }
 }
@@ -228,16 +246,69 @@ template <int R>
 SM_HD void pass_scatter(const float* x, float* lds, int N, int Ns, int T, int t) {
     constexpr int MB = EMAX / R;
     const int nb = N / R;
+    const bool big = (Ns & 31) == 0;                                   // i*Ns is a multiple of 32
+    const bool small = Ns < 32 && (32 % Ns) == 0 && ((Ns * R) & 31) == 0;   // (j-k)*R is a multiple of 32, k + i*Ns never carries
+    if (big || small) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        const int j = t + m * T;
-        if (j < nb) {
-            const int k = j % Ns;
-            const int base = (j - k) * R + k;
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+                const int k = j % Ns;
+                const int base0 = (j - k) * R;
+                float* b = lds + (big ? lpad(base0 + k) : lpad(base0) + k);
 #pragma unroll
-            for (int i = 0; i < R; ++i) lds[lpad(base + i * Ns)] = x[m * R + i];
+                for (int i = 0; i < R; ++i) b[i * Ns + ((i * Ns) >> 5)] = x[m * R + i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+                const int k = j % Ns;
+                const int base = (j - k) * R + k;
+#pragma unroll
+                for (int i = 0; i < R; ++i) lds[lpad(base + i * Ns)] = x[m * R + i];
+            }
         }
     }
+}
+
+SM_HD void cmul(float& ar, float& ai, float br, float bi) {
+    const float r = ar * br - ai * bi;
+    ai = ar * bi + ai * br;
+    ar = r;
+}
+
+// multiply x[i] by w^i, i = 1..R-1, w = W_{Ns*R}^k.  Only the powers w^(2^b) are
+// loaded from the table (exact to half an ulp); the others are products of at
+// most three of them, so a radix-16 butterfly costs 4 table loads instead of 15
+// and keeps 16 instead of 30 registers of twiddles alive.
+template <int R>
+SM_HD void apply_twiddles(float* xr, float* xi, const cf2* tw, int kidx) {
+    constexpr int LOGR = R <= 2 ? 1 : R <= 4 ? 2 : R <= 8 ? 3 : R <= 16 ? 4 : 5;
+    constexpr int HALF = 1 << (LOGR - 1);              // top power of two used
+    float pr[LOGR], pi[LOGR];
+#pragma unroll
+    for (int b = 0; b < LOGR; ++b) {
+        if ((1 << b) < R) { const cf2 w = tw[kidx << b]; pr[b] = w.x; pi[b] = w.y; } else { pr[b] = 1.f; pi[b] = 0.f; }
+    }
+    // low powers w^1 .. w^(HALF-1)
+    float lr[HALF], li[HALF];
+    lr[0] = 1.f; li[0] = 0.f;
+    static_for<1, HALF>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int top = (i >= 16) ? 4 : (i >= 8) ? 3 : (i >= 4) ? 2 : (i >= 2) ? 1 : 0;
+        constexpr int rest = i - (1 << top);
+        if constexpr (rest == 0) { lr[i] = pr[top]; li[i] = pi[top]; }
+        else { lr[i] = lr[rest]; li[i] = li[rest]; cmul(lr[i], li[i], pr[top], pi[top]); }
+    });
+    static_for<1, R>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int lo = i & (HALF - 1);
+        if constexpr (lo != 0) cmul(xr[i], xi[i], lr[lo], li[lo]);
+        if constexpr (i >= HALF) cmul(xr[i], xi[i], pr[LOGR - 1], pi[LOGR - 1]);
+    });
 }
 
 template <int R>
@@ -251,12 +322,14 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
         if (j < nb) {
             if (Ns > 1) {
                 const int k = j % Ns;
+                if constexpr (R == 2 || R == 4 || R == 8 || R == 16 || R == 32) {
+                    apply_twiddles<R>(xr + m * R, xi + m * R, tw, k * tstep);
+                } else {
 #pragma unroll
-                for (int i = 1; i < R; ++i) {
-                    const cf2 w = tw[i * k * tstep];
-                    const float r = xr[m * R + i], q = xi[m * R + i];
-                    xr[m * R + i] = r * w.x - q * w.y;
-                    xi[m * R + i] = r * w.y + q * w.x;
+                    for (int i = 1; i < R; ++i) {
+                        const cf2 w = tw[i * k * tstep];
+                        cmul(xr[m * R + i], xi[m * R + i], w.x, w.y);
+                    }
                 }
             }
             Dft<R>::run(xr + m * R, xi + m * R);

@@ -113,6 +113,19 @@ SM_HD float load_sig1(const SigDesc& s, size_t i) {
 // C < 0: the planes hold a full spectrum, every bin counts once.
 SM_HD int bin_weight(int k2, int C) { return (C < 0 || k2 == 0 || (2 * k2 == C)) ? 1 : 2; }
 
+// XCD-aware placement for the strided (column) passes.  Work-groups are dealt
+// round-robin over the 8 XCDs (blocks b and b+8 share an L2): the G work-groups
+// that touch the same 128-byte lines get block ids that are equal mod 8 and
+// adjacent in dispatch order, so a line is fetched from HBM once per XCD-L2 and
+// partial-line writes merge in that L2.  Speed only, never correctness.
+// Returns the logical index for block id `bid`; the grid must be padded to a
+// multiple of 8*G and logical indices >= count do nothing.
+SM_HD int xcd_remap(int bid, int G) {
+    const int per = 8 * G;
+    const int y = bid / per, i = (bid % per) / 8, x = bid % 8;
+    return (y * 8 + x) * G + i;
+}
+
 struct FftState {
     float xr[EREG];
     float xi[EREG];
@@ -279,8 +292,9 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const int LF = plan_lds<P>(pl);
     const int ng = p.nsig;
     const int bid = ex.bid();
-    const int k2 = (ng == 2) ? bid : bid / 2;
+    const int k2 = (ng == 2) ? xcd_remap(bid, 8) : bid / 2;     // 8 bins of 16 B share a 128-B line
     const int slot0 = (ng == 2) ? 0 : bid % 2;
+    if (k2 >= p.Cb) return;
     uint32_t* lhist = (uint32_t*)(lds + ng * LF);
 
     ex.each(st, [&](int tid, FftState& s) {
@@ -411,7 +425,8 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
     const FftPlanDev& pl = p.plan;
     const int T = plan_T<P>(pl), R = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
-    const int bid = ex.bid();
+    const int bid = xcd_remap(ex.bid(), 16 / S);      // 16 bins of 8 B share a 128-B line
+    if (bid * S >= p.Cb) return;
     const float thr = p.cull_thr ? *p.cull_thr : 0.f;
 
     ex.each(st, [&](int tid, FftState& s) {

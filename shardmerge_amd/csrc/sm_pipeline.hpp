@@ -295,7 +295,7 @@ class Pipeline {
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
         p.hist = hist ? d_hist() : nullptr;
-        const int grid = p.Cb * (p.nsig == 2 ? 1 : 2);
+        const int grid = p.nsig == 2 ? (int)round_up((size_t)p.Cb, 64) : p.Cb * 2;
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nsig * p.plan.lds_floats + HIST1_BINS) * 4;
         launch_fft<KF2>(p.plan, grid, p.nsig * p.plan.T, lds, p);
         return SMHIP_OK;
@@ -355,7 +355,7 @@ class Pipeline {
         a.s = (2 * a.plan.T <= 1024) ? 2 : 1;
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
-        const int grid1 = (Cb + a.s - 1) / a.s;
+        const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
         if (a.s == 2) launch_fft<KI1x2>(a.plan, grid1, 2 * a.plan.T, lds1, a);
         else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
 
