@@ -122,6 +122,10 @@ typedef struct {
 int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf16, float* delta_out,
                       smhip_layer_report* report, void* stream);
 
+/* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
+ *      lists (0 = default) so that the overflow fallback can be exercised. -------- */
+int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
+
 /* ---- profiling: per-kernel device time measured with HIP events on the
  *      caller's stream (bench.py's roofline leg) ---------------------------- */
 int smhip_profile_enable(smhip_ctx* ctx, int on);

@@ -92,6 +92,7 @@ class SmhipLibrary:
                                                      C.POINTER(I), C.POINTER(BlendInfo), P]
         d.smhip_task_arithmetic_fft2.argtypes = [P, P, P, I, I, D, I, P, P]
         d.smhip_merge_layer.argtypes = [P, C.POINTER(LayerDesc), P, P, C.POINTER(LayerReport), P]
+        d.smhip_debug_option.argtypes = [P, C.c_char_p, C.c_long]
         d.smhip_profile_enable.argtypes = [P, I]
         d.smhip_profile_reset.argtypes = [P]
         d.smhip_profile_count.argtypes = [P]
@@ -133,6 +134,9 @@ class Context:
 
     def workspace_bytes(self) -> int:
         return int(self.lib.dll.smhip_workspace_bytes(self.h))
+
+    def debug_option(self, key: str, value: int):
+        self.check(self.lib.dll.smhip_debug_option(self.h, key.encode(), int(value)))
 
     def profile(self, on: bool):
         self.check(self.lib.dll.smhip_profile_enable(self.h, 1 if on else 0))

@@ -126,6 +126,24 @@ SM_HD int xcd_remap(int bid, int G) {
     return (y * 8 + x) * G + i;
 }
 
+// multiplicity of plane element i (planes are [Cb][R]): 1 inside column 0 and
+// column C/2, else 2 - two range tests instead of a division per element
+struct WeightRanges {
+    size_t hi0, loN, hiN;
+    int full;
+};
+SM_HD WeightRanges weight_ranges(int R, int C) {
+    WeightRanges w;
+    w.full = C < 0;
+    w.hi0 = (size_t)R;
+    if (C >= 0 && (C % 2) == 0 && C > 0) { w.loN = (size_t)(C / 2) * R; w.hiN = w.loN + R; }
+    else { w.loN = w.hiN = 0; }
+    return w;
+}
+SM_HD uint32_t weight_at(const WeightRanges& w, size_t i) {
+    return (w.full || i < w.hi0 || (i >= w.loN && i < w.hiN)) ? 1u : 2u;
+}
+
 struct FftState {
     float xr[EREG];
     float xi[EREG];
@@ -692,6 +710,11 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
 // =====================================================================
 struct EmptyState { double red[8]; };
 
+SM_HD int sgn(float v) { return (v > 0.f) - (v < 0.f); }
+// torch.sign(NaN) = NaN and NaN == NaN is False: NaNs never "agree"
+SM_HD bool same_sign(float a, float b) { return !is_nan(a) && !is_nan(b) && sgn(a) == sgn(b); }
+
+
 // selection state (device memory): exact k-th smallest key by radix levels
 struct SelState {
     unsigned long long rank;    // in: 0-based rank wanted; updated to rank within the prefix
@@ -709,6 +732,7 @@ struct HistParams {
     const SelState* sel;
     unsigned long long* hist;
     int chunks;                         // quads per thread
+    const uint32_t* only_if;            // when set: run only if *only_if != 0 (fallback after a list overflow)
 };
 
 // load up to 4 consecutive plane values starting at element i0
@@ -734,7 +758,9 @@ SM_HD void k_hist(Ex& ex, const HistParams& p) {
     const int nbins = p.level == 1 ? HIST1_BINS : HIST_LO_BINS;
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
+    if (p.only_if && !*p.only_if) return;
     const uint32_t prefix = p.sel->prefix;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
     ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < nbins; b += nt) lh[b] = 0; });
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
@@ -751,7 +777,7 @@ SM_HD void k_hist(Ex& ex, const HistParams& p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (e < n) {
-                        const uint32_t w = (uint32_t)bin_weight((int)((i0 + e) / p.R), p.C);
+                        const uint32_t w = weight_at(wr, i0 + e);
                         const uint32_t key = f2u(v[e]) & 0x7fffffffu;
                         if (p.level == 1) ex.lds_atomic_add(&lh[key >> 20], w);
                         else if (p.level == 2) { if ((key >> 20) == prefix) ex.lds_atomic_add(&lh[(key >> 10) & 1023u], w); }
@@ -767,6 +793,201 @@ SM_HD void k_hist(Ex& ex, const HistParams& p) {
             const uint32_t v = lh[b];
             if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
         }
+    });
+}
+
+// ---------------------------------------------------------------------------
+// Level-2 selection pass with candidate compaction (and, for the cutoff
+// threshold, the masked slerp sums fused in).
+//
+// After level 1 the k-th smallest key is known to lie in bin B1 = sel->prefix
+// (key >> 20).  One streaming pass over the plane(s)
+//   * histograms bits [19:10] of the keys in B1 (as k_hist level 2 does), and
+//   * appends those keys (~1 % of the data) to a candidate list, so that level 3
+//     runs on the list instead of re-reading the planes;
+//   * with `fuse_reduce`: accumulates the slerp-class sums over every bin whose
+//     class does not depend on the exact threshold (|r1|'s level-1 bin above B1),
+//     and appends the undecided bins (|r1| in B1, signs agree) to a pair list that
+//     k_reduce_cand settles once the threshold is known.
+// Lists are staged in LDS and appended with one global atomic per work-group.
+// Any overflow (staging or list capacity) raises *overflow; the caller then
+// falls back to the plain full passes (k_hist level 3 / k_reduce), which exit
+// immediately otherwise.
+// ---------------------------------------------------------------------------
+constexpr int STAGE_KEYS = 2048;     // per work-group staging (expected ~160 keys / ~40 pairs)
+constexpr int STAGE_PAIRS = 1024;
+struct CandLists {
+    uint32_t* keys;        // key | (weight-1) << 31
+    cf4* pairs;            // (r0, r1, weight, 0)
+    uint32_t cap_keys, cap_pairs;
+    uint32_t* counters;    // [0] n_keys, [1] n_pairs, [2] overflow
+};
+struct Select2Params {
+    const float* X; const float* Y;     // Y may be null
+    int R, C, Cb;
+    int vec4;
+    const SelState* sel;
+    unsigned long long* hist;           // HIST_LO_BINS
+    CandLists cand;
+    int fuse_reduce;                    // needs Y: X = Re a, Y = Re b
+    double* partials;                   // [grid][4] when fuse_reduce
+    int chunks;
+};
+
+template <class Ex>
+SM_HD void k_select2(Ex& ex, const Select2Params& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    uint32_t* lctl = lh + HIST_LO_BINS;                 // [0] nkeys [1] npairs [2] base keys [3] base pairs
+    uint32_t* lkeys = lctl + 8;
+    cf4* lpairs = (cf4*)(lkeys + STAGE_KEYS);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    const uint32_t prefix = p.sel->prefix;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0;
+        if (tid < 8) lctl[tid] = 0;
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t qi = start + (size_t)c * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            float a[4], b[4];
+            const int n = load_quad(p.X, i0, total, p.vec4, a);
+            if (p.Y) load_quad(p.Y, i0, total, p.vec4, b);
+            float q00 = 0.f, q01 = 0.f, q11 = 0.f, qc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < n) {
+                    const uint32_t w = weight_at(wr, i0 + e);
+                    const uint32_t ka = f2u(a[e]) & 0x7fffffffu;
+                    if ((ka >> 20) == prefix) {
+                        ex.lds_atomic_add(&lh[(ka >> 10) & 1023u], w);
+                        const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
+                        if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = ka | ((w - 1u) << 31);
+                    }
+                    if (p.Y) {
+                        const uint32_t kb = f2u(b[e]) & 0x7fffffffu;
+                        const uint32_t binb = kb >> 20;
+                        if (binb == prefix) {
+                            ex.lds_atomic_add(&lh[(kb >> 10) & 1023u], w);
+                            const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
+                            if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = kb | ((w - 1u) << 31);
+                        }
+                        if (p.fuse_reduce && same_sign(a[e], b[e])) {
+                            if (binb > prefix) {            // |r1| >= threshold whatever its low bits
+                                const float wf = (float)w;
+                                q00 += wf * a[e] * a[e]; q01 += wf * a[e] * b[e]; q11 += wf * b[e] * b[e]; qc += wf;
+                            } else if (binb == prefix) {
+                                const uint32_t pos = ex.lds_atomic_add_ret(&lctl[1], 1u);
+                                if (pos < (uint32_t)STAGE_PAIRS) { cf4 v = {a[e], b[e], (float)w, 0.f}; lpairs[pos] = v; }
+                            }
+                        }
+                    }
+                }
+            }
+            s00 += q00; s01 += q01; s11 += q11; cnt += qc;
+        }
+        s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid == 0) {
+            uint32_t nk = lctl[0], np = lctl[1];
+            bool over = false;
+            if (nk > (uint32_t)STAGE_KEYS) { nk = STAGE_KEYS; over = true; }
+            if (np > (uint32_t)STAGE_PAIRS) { np = STAGE_PAIRS; over = true; }
+            const uint32_t bk = nk ? ex.global_atomic_add_ret_u32(&p.cand.counters[0], nk) : 0u;
+            const uint32_t bp = np ? ex.global_atomic_add_ret_u32(&p.cand.counters[1], np) : 0u;
+            if (bk + nk > p.cand.cap_keys || bp + np > p.cand.cap_pairs) over = true;
+            if (over) ex.global_atomic_or_u32(&p.cand.counters[2], 1u);
+            lctl[0] = nk; lctl[1] = np; lctl[2] = bk; lctl[3] = bp;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int b = tid; b < HIST_LO_BINS; b += nt) {
+            const uint32_t v = lh[b];
+            if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+        }
+        const uint32_t nk = lctl[0], np = lctl[1], bk = lctl[2], bp = lctl[3];
+        for (uint32_t q = tid; q < nk; q += nt) if (bk + q < p.cand.cap_keys) p.cand.keys[bk + q] = lkeys[q];
+        for (uint32_t q = tid; q < np; q += nt) if (bp + q < p.cand.cap_pairs) p.cand.pairs[bp + q] = lpairs[q];
+    });
+    if (p.fuse_reduce) {
+        ex.sync();
+        ex.template block_sum<4>(st, [&](const double* tot) {
+            for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
+        });
+    }
+}
+
+// level 3 on the candidate list (or nothing when the list overflowed)
+struct Select3Params {
+    CandLists cand;
+    const SelState* sel;
+    unsigned long long* hist;
+};
+template <class Ex>
+SM_HD void k_select3(Ex& ex, const Select3Params& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    if (p.cand.counters[2]) return;                    // overflow: the full pass does it
+    const uint32_t n = p.cand.counters[0];
+    const uint32_t prefix = p.sel->prefix;
+    ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0; });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (size_t q = (size_t)ex.bid() * nt + tid; q < n; q += (size_t)ex.nblocks() * nt) {
+            const uint32_t v = p.cand.keys[q];
+            const uint32_t key = v & 0x7fffffffu;
+            if ((key >> 10) == prefix) ex.lds_atomic_add(&lh[key & 1023u], 1u + (v >> 31));
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int b = tid; b < HIST_LO_BINS; b += nt) {
+            const uint32_t v = lh[b];
+            if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+        }
+    });
+}
+
+// settle the undecided pairs once the cutoff threshold is known
+struct ReduceCandParams {
+    CandLists cand;
+    const float* thr;
+    double* partials;          // [nblocks][4], appended after the fused pass's partials
+};
+template <class Ex>
+SM_HD void k_reduce_cand(Ex& ex, const ReduceCandParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const bool over = p.cand.counters[2] != 0;
+    const uint32_t n = over ? 0u : p.cand.counters[1];
+    const float thr = *p.thr;
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
+        for (size_t q = (size_t)ex.bid() * nt + tid; q < n; q += (size_t)ex.nblocks() * nt) {
+            const cf4 v = p.cand.pairs[q];
+            if (!(fabsf(v.y) < thr)) {
+                s00 += (double)v.z * v.x * v.x; s01 += (double)v.z * v.x * v.y; s11 += (double)v.z * v.y * v.y; cnt += v.z;
+            }
+        }
+        s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
     });
 }
 
@@ -846,11 +1067,9 @@ struct ReduceParams {
     const float* thr;           // device scalar (cutoff threshold) or null (-> 0)
     double* partials;           // [grid][4]: s00, s01, s11, count
     int chunks;
+    const uint32_t* only_if;    // when set: if *only_if == 0 write zero partials and leave
 };
 
-SM_HD int sgn(float v) { return (v > 0.f) - (v < 0.f); }
-// torch.sign(NaN) = NaN and NaN == NaN is False: NaNs never "agree"
-SM_HD bool same_sign(float a, float b) { return !is_nan(a) && !is_nan(b) && sgn(a) == sgn(b); }
 
 template <class Ex>
 SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
@@ -860,10 +1079,12 @@ SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
     const float thr = p.thr ? *p.thr : 0.f;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const bool skip = p.only_if && !*p.only_if;
     ex.each(st, [&](int tid, EmptyState& s) {
         double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
-        for (int c = 0; c < p.chunks; ++c) {
+        for (int c = 0; c < p.chunks && !skip; ++c) {
             const size_t qi = start + (size_t)c * nt + tid;
             if (qi >= nquad) break;
             const size_t i0 = 4 * qi;
@@ -874,7 +1095,7 @@ SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e < n && same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr)) {
-                    const float w = (float)bin_weight((int)((i0 + e) / p.R), p.C);
+                    const float w = (float)weight_at(wr, i0 + e);
                     q00 += w * a[e] * a[e]; q01 += w * a[e] * b[e]; q11 += w * b[e] * b[e]; qc += w;
                 }
             }
@@ -888,7 +1109,9 @@ SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
 }
 
 struct SlerpConstParams {
-    const double* partials; int nparts;
+    const double* partials; int nparts;      // fused/definite part + candidate part (contiguous)
+    const double* fallback; int nfallback;   // full-pass partials, used instead when *overflow != 0
+    const uint32_t* overflow;
     const float* thr;           // device scalar or null (-> 0)
     float t;
     BlendConsts* out;
@@ -902,11 +1125,14 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
     const int nt = ex.nthreads();
+    const bool use_fb = p.overflow && *p.overflow;
+    const double* src = use_fb ? p.fallback : p.partials;
+    const int nsrc = use_fb ? p.nfallback : p.nparts;
     ex.each(st, [&](int tid, EmptyState& s) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int i = tid; i < p.nparts; i += nt) {
-            a0 += p.partials[4 * i]; a1 += p.partials[4 * i + 1];
-            a2 += p.partials[4 * i + 2]; a3 += p.partials[4 * i + 3];
+        for (int i = tid; i < nsrc; i += nt) {
+            a0 += src[4 * i]; a1 += src[4 * i + 1];
+            a2 += src[4 * i + 2]; a3 += src[4 * i + 3];
         }
         s.red[0] = a0; s.red[1] = a1; s.red[2] = a2; s.red[3] = a3;
     });
@@ -983,6 +1209,7 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
     BlendConsts c;
     memset(&c, 0, sizeof(c));
     if (p.mode == BLEND_SLERP) c = *p.consts;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
     if (p.hist) {
         ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
         ex.sync();
@@ -1009,7 +1236,7 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
                 for (int e = 0; e < 4; ++e) {
                     if (e < n) {
                         const uint32_t key = f2u(r[e]) & 0x7fffffffu;
-                        ex.lds_atomic_add(&lh[key >> 20], (uint32_t)bin_weight((int)((i0 + e) / p.R), p.C));
+                        ex.lds_atomic_add(&lh[key >> 20], weight_at(wr, i0 + e));
                     }
                 }
             }

@@ -56,6 +56,9 @@ inline bool plan_matches(const FftPlanDev& pl) {
 }
 SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
+SM_KERNEL_TAG(KSelect2, Select2Params, "select_lvl2", k_select2(ex, p))
+SM_KERNEL_TAG(KSelect3, Select3Params, "select_lvl3_cand", k_select3(ex, p))
+SM_KERNEL_TAG(KReduceCand, ReduceCandParams, "slerp_reduce_cand", k_reduce_cand(ex, p))
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
 SM_KERNEL_TAG(KSlerpConsts, SlerpConstParams, "slerp_consts", k_slerp_consts(ex, p))
 SM_KERNEL_TAG(KSumPartials, SumPartialsParams, "sum_partials", k_sum_partials(ex, p))
@@ -129,11 +132,12 @@ class Pipeline {
     B be;
     std::string err;
     void* stream = nullptr;
+    uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
 
     explicit Pipeline(int device) : be(device) {}
     ~Pipeline() {
         for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
-        for (Buffer* b : {&t1_, &planes_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        for (Buffer* b : {&cand_, &t1_, &planes_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
     }
 
@@ -184,7 +188,7 @@ class Pipeline {
         return SMHIP_OK;
     }
     size_t workspace_bytes() const {
-        size_t t = t1_.cap + planes_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
+        size_t t = cand_.cap + t1_.cap + planes_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
         for (const Buffer& b : inter_) t += b.cap;
         return t;
     }
@@ -211,6 +215,11 @@ class Pipeline {
         int rc;
         if ((rc = ensure(t1_, (size_t)R * g.pitch4 * sizeof(cf4)))) return rc;
         if ((rc = ensure(planes_, 4 * g.plane_floats * sizeof(float)))) return rc;
+        {   // candidate lists of the selection passes: ~1 % of the data is expected
+            const size_t ck = std::max<size_t>(1 << 16, g.plane_floats / 4), cp = std::max<size_t>(1 << 15, g.plane_floats / 16);
+            if ((rc = ensure(cand_, ck * 4 + cp * 16))) return rc;
+            cap_keys_ = (uint32_t)std::min<size_t>(ck, 0xffffffffu); cap_pairs_ = (uint32_t)std::min<size_t>(cp, 0xffffffffu);
+        }
         if (!small_.p) {
             if ((rc = ensure(small_, SMALL_BYTES))) return rc;
             be.memset(small_.p, 0, SMALL_BYTES, stream);
@@ -223,6 +232,7 @@ class Pipeline {
     static constexpr size_t OFF_CONSTS = OFF_SEL + 2 * sizeof(SelState);   // BlendConsts
     static constexpr size_t OFF_THR = OFF_CONSTS + 256;                    // float thr[4]
     static constexpr size_t OFF_FLAGS = OFF_THR + 64;                      // u32[8]
+    static constexpr size_t OFF_CANDCTR = OFF_FLAGS + 32;                  // u32[4]: n_keys, n_pairs, overflow
     static constexpr size_t OFF_NORM2 = OFF_FLAGS + 64;                    // double[2]
     static constexpr size_t OFF_PART = OFF_NORM2 + 64;                     // double partials
     static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
@@ -232,6 +242,14 @@ class Pipeline {
     BlendConsts* d_consts() { return (BlendConsts*)((char*)small_.p + OFF_CONSTS); }
     float* d_thr(int i) { return (float*)((char*)small_.p + OFF_THR) + i; }
     uint32_t* d_flags() { return (uint32_t*)((char*)small_.p + OFF_FLAGS); }
+    uint32_t* d_candctr() { return (uint32_t*)((char*)small_.p + OFF_CANDCTR); }
+    CandLists cand_lists() {
+        CandLists c;
+        c.keys = (uint32_t*)cand_.p; c.pairs = (cf4*)((char*)cand_.p + (size_t)cap_keys_ * 4);
+        c.cap_keys = cap_keys_; c.cap_pairs = cap_pairs_; c.counters = d_candctr();
+        if (debug_cand_cap) { c.cap_keys = std::min(c.cap_keys, debug_cand_cap); c.cap_pairs = std::min(c.cap_pairs, debug_cand_cap); }
+        return c;
+    }
     double* d_norm2() { return (double*)((char*)small_.p + OFF_NORM2); }
     double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
     float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
@@ -301,24 +319,51 @@ class Pipeline {
         return SMHIP_OK;
     }
 
-    // exact k-th smallest of |X| (and |Y|) with bin multiplicities -> *thr_out
-    void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out) {
+    // exact k-th smallest of |X| (and |Y|) with bin multiplicities -> *thr_out.
+    // Level 1 (11 bits) may already sit in d_hist() (fused into F2 / blend); level 2
+    // (10 bits) is one streaming pass that also compacts the candidates, level 3 (10
+    // bits) runs on the candidate list.  With fuse_reduce the level-2 pass also takes
+    // the slerp-class sums (then *nparts_out partial rows of 4 doubles sit in d_part()).
+    static constexpr int CAND_GRID = 32;
+    void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out,
+                    bool fuse_reduce = false, int* nparts_out = nullptr) {
         const size_t total = (size_t)g.Cb * g.R;
         HistParams h;
         h.X = X; h.Y = Y; h.R = g.R; h.C = g.Cw; h.Cb = g.Cb; h.vec4 = vec4(g); h.sel = d_sel(0);
-        h.hist = d_hist(); h.chunks = 8;
+        h.hist = d_hist(); h.chunks = 8; h.only_if = nullptr;
         const int hgrid = stream_grid((total + 3) / 4, 256, h.chunks);
         const size_t hlds = (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4;
+        const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256) * 4;
         ScanParams s;
         s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out;
         if (!level1_done) { h.level = 1; be.template launch<KHist>(hgrid, 256, hlds, h, stream); }
         s.nbins = HIST1_BINS; s.shift = 11; s.final_level = 0; s.init = 1; s.rank_init = rank;
-        be.template launch<KScan>(1, 256, (LDS_SCRATCH_FLOATS + 2 * 256) * 4, s, stream);
-        for (int level = 2; level <= 3; ++level) {
-            h.level = level;
-            be.template launch<KHist>(hgrid, 256, hlds, h, stream);
-            s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = (level == 3); s.init = 0;
-            be.template launch<KScan>(1, 256, (LDS_SCRATCH_FLOATS + 2 * 256) * 4, s, stream);
+        be.template launch<KScan>(1, 256, scan_lds, s, stream);
+
+        be.memset(d_candctr(), 0, 16, stream);
+        Select2Params q;
+        q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0); q.hist = d_hist();
+        q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part(); q.chunks = 8;
+        int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
+        while ((size_t)(2 * grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
+        const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);
+        be.template launch<KSelect2>(grid2, 256, lds2, q, stream);
+        s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = 0; s.init = 0;
+        be.template launch<KScan>(1, 256, scan_lds, s, stream);
+
+        Select3Params t3;
+        t3.cand = q.cand; t3.sel = d_sel(0); t3.hist = d_hist();
+        be.template launch<KSelect3>(CAND_GRID, 256, (LDS_SCRATCH_FLOATS + HIST_LO_BINS) * 4, t3, stream);
+        h.level = 3; h.only_if = d_candctr() + 2;            // full pass only after a list overflow
+        be.template launch<KHist>(hgrid, 256, hlds, h, stream);
+        s.final_level = 1;
+        be.template launch<KScan>(1, 256, scan_lds, s, stream);
+
+        if (q.fuse_reduce) {
+            ReduceCandParams rc;
+            rc.cand = q.cand; rc.thr = thr_out; rc.partials = d_part() + 4 * (size_t)grid2;
+            be.template launch<KReduceCand>(CAND_GRID, 256, LDS_SCRATCH_FLOATS * 4, rc, stream);
+            if (nparts_out) *nparts_out = grid2 + CAND_GRID;
         }
     }
 
@@ -332,17 +377,28 @@ class Pipeline {
         be.template launch<KBlend>(stream_grid((total + 3) / 4, 256, b.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, b, stream);
     }
 
-    // masked slerp sums + constants (reference functions.py:36-43 on the slerp class)
-    void run_slerp_consts(const Geo& g, bool have_thr, float t) {
+    // masked slerp sums + constants (reference functions.py:36-43 on the slerp class).
+    // fused_parts > 0: the level-2 selection pass already left the sums in d_part()
+    // (valid unless the candidate lists overflowed, in which case the full pass below
+    // - which otherwise exits at once - provides them).
+    void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts) {
         const size_t total = (size_t)g.Cb * g.R;
         ReduceParams r;
         r.reA = plane(g, P_REA); r.reB = plane(g, P_REB); r.R = g.R; r.C = g.Cw; r.Cb = g.Cb; r.vec4 = vec4(g);
-        r.thr = have_thr ? d_thr(0) : nullptr; r.partials = d_part(); r.chunks = 16;
+        r.thr = have_thr ? d_thr(0) : nullptr; r.chunks = 16;
         int grid = stream_grid((total + 3) / 4, 256, r.chunks);
-        while ((size_t)grid * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
+        while ((size_t)(grid + fused_parts) * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
+        r.partials = d_part() + 4 * (size_t)fused_parts;
+        r.only_if = fused_parts > 0 ? d_candctr() + 2 : nullptr;
         be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
         SlerpConstParams c;
-        c.partials = d_part(); c.nparts = grid; c.thr = r.thr; c.t = t; c.out = d_consts();
+        if (fused_parts > 0) {
+            c.partials = d_part(); c.nparts = fused_parts;
+            c.fallback = r.partials; c.nfallback = grid; c.overflow = d_candctr() + 2;
+        } else {
+            c.partials = r.partials; c.nparts = grid; c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
+        }
+        c.thr = r.thr; c.t = t; c.out = d_consts();
         be.template launch<KSlerpConsts>(1, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
     }
 
@@ -421,9 +477,11 @@ class Pipeline {
         have_cull = false;
         if (mode == BLEND_SLERP) {
             const bool have_cut = cutoff_pct > 0;
+            int fused = 0;
             if (have_cut)
-                run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0));
-            run_slerp_consts(g, have_cut, (float)t);
+                run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0),
+                           true, &fused);
+            run_slerp_consts(g, have_cut, (float)t, fused);
             run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
             if (cull_pct > 0) {
                 run_select(g, plane(g, P_RER), nullptr, pct_index(nfull, cull_pct), true, d_thr(1));
@@ -869,7 +927,8 @@ class Pipeline {
     // profiling table lives in the backend
   private:
     std::map<int, HostPlan> plans_;
-    Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_;
+    Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
+    uint32_t cap_keys_ = 0, cap_pairs_ = 0;
     std::vector<Buffer> inter_;
     std::vector<double> host_part_;
 };

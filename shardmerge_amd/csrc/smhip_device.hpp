@@ -11,6 +11,7 @@ struct DeviceExec {
     template <class S> struct State { using value_type = S; S s; };
     __device__ __forceinline__ int bid() const { return blockIdx.x; }
     __device__ __forceinline__ int nthreads() const { return blockDim.x; }
+    __device__ __forceinline__ int nblocks() const { return gridDim.x; }
     __device__ __forceinline__ float* lds() {
         extern __shared__ __attribute__((aligned(16))) float sm_dyn_lds[];
         return sm_dyn_lds;
@@ -19,6 +20,8 @@ struct DeviceExec {
     template <class S, class F> __device__ __forceinline__ void each(State<S>& st, F&& f) { f((int)threadIdx.x, st.s); }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ void lds_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+    __device__ __forceinline__ uint32_t lds_atomic_add_ret(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ uint32_t global_atomic_add_ret_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ void global_atomic_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
     __device__ __forceinline__ void global_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
     __device__ __forceinline__ void global_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }

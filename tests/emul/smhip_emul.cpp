@@ -23,6 +23,8 @@ struct HostExec {
     template <class S> struct State { using value_type = S; std::vector<S> v; };
     int bid_, nt_;
     std::vector<float>* lds_;
+    int nblk_ = 1;
+    int nblocks() const { return nblk_; }
     int bid() const { return bid_; }
     int nthreads() const { return nt_; }
     float* lds() { return lds_->data(); }
@@ -30,6 +32,8 @@ struct HostExec {
     template <class S, class F> void each(State<S>& st, F&& f) { for (int t = 0; t < nt_; ++t) f(t, st.v[t]); }
     void sync() {}
     void lds_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
+    uint32_t lds_atomic_add_ret(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
+    uint32_t global_atomic_add_ret_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
     void global_atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
     void global_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
     void global_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
@@ -62,7 +66,7 @@ struct HostBackend {
         for (int b = 0; b < grid; ++b) {
             // poison LDS so that reads of never-written words show up as NaNs
             for (auto& x : lds) x = std::nanf("");
-            HostExec ex{b, block, &lds};
+            HostExec ex{b, block, &lds, grid};
             K::run(ex, p);
         }
         if (profiling) {

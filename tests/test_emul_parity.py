@@ -71,3 +71,36 @@ def test_nan_is_zeroed(engine):
     ft2[2, 3] = float("nan")
     out, rep = engine.merge_layer([ft2], [base], [1.0], base)
     assert rep.nan_final == 1 and out[2, 3] == 0 and not torch.isnan(out.float()).any()
+
+
+def test_candidate_list_overflow_falls_back(engine, golden):
+    """The level-2 selection pass compacts ~1 % of the data into candidate lists; when
+    a list overflows, the plain full passes must produce the very same result."""
+    case = [c for c in gi.PAIR_CASES if c["id"] == "pair_256_mix"][0]
+    a, b = gi.pair_input(case)
+    kw = dict(b=case["b"], t_sum=case["t_sum"], cutoff_pct=case["cutoff"], cull_pct=case["cull"])
+    ref, _, _, rep0 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
+    engine.ctx.debug_option("cand_cap", 7)
+    try:
+        out, _, _, rep1 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
+    finally:
+        engine.ctx.debug_option("cand_cap", 0)
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())   # sums associate differently: ulps
+    assert rep1.cutoff_threshold == rep0.cutoff_threshold and rep1.cull_threshold == rep0.cull_threshold
+    assert rep1.n_slerp == rep0.n_slerp and rep1.s01 == pytest.approx(rep0.s01, rel=1e-9)
+
+
+def test_heavy_ties(engine):
+    """Quantised inputs give spectra with many exactly equal magnitudes (and exact
+    zeros): the order statistics must still be the reference's."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-2, 3, (64, 64), generator=g).float() * 0.25
+    b = torch.randint(-2, 3, (64, 64), generator=g).float() * 0.25
+    a[:, ::2] = 0
+    tr = so.BlendTrace()
+    ref, n0, n1 = so.merge_tensors_fft2_slerp(a, b, 0.5, cutoff_pct=0.08, cull_pct=0.2, trace=tr)
+    out, m0, m1, rep = engine.merge_tensors_fft2_slerp(a, b, 0.5, cutoff_pct=0.08, cull_pct=0.2)
+    total, resid = pc.spectral_residual(out, ref, drop=64)
+    assert abs(rep.cutoff_threshold - tr.cutoff_threshold) <= 1e-5 * max(tr.cutoff_threshold, 1e-6)
+    assert resid < 1e-4
