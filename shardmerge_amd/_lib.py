@@ -153,7 +153,8 @@ class Context:
         return out
 
 
-_HIP_LIB_PATH = Path(__file__).resolve().parent / "libshardmerge_hip.so"
+# SHARDMERGE_HIP_LIB selects another build of the same HIP library (tuning experiments)
+_HIP_LIB_PATH = Path(os.environ.get("SHARDMERGE_HIP_LIB") or Path(__file__).resolve().parent / "libshardmerge_hip.so")
 _lib: Optional[SmhipLibrary] = None
 
 

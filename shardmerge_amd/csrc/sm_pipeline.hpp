@@ -20,6 +20,7 @@ namespace smhip {
 #define SM_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                      \
     struct Tag {                                                                     \
         using Params = ParamsT;                                                      \
+        static constexpr int waves = 4;                                              \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
@@ -27,6 +28,7 @@ namespace smhip {
 #define SM_FFT_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                  \
     template <class P> struct Tag {                                                  \
         using Params = ParamsT;                                                      \
+        static constexpr int waves = P::waves;                                       \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
@@ -38,18 +40,44 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p))
 
 // lengths that get straight-line kernels; must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
-#define SM_STATIC_PLANS(X)          \
-    X(SPlan<1024, 64, 32, 32>)      \
-    X(SPlan<2048, 64, 16, 16, 8>)   \
-    X(SPlan<4096, 128, 16, 16, 16>) \
-    X(SPlan<8192, 256, 32, 16, 16>) \
-    X(SPlan<16384, 512, 32, 32, 16>)\
-    X(SPlan<14336, 512, 16, 16, 8, 7>) \
-    X(SPlan<28672, 1024, 16, 16, 16, 7>)
+// experiment knobs for the 8192-point plan (override with -D on the hipcc line)
+#ifndef SM_T8192
+#define SM_T8192 256
+#define SM_W8192 4
+#define SM_R8192 32, 16, 16
+#endif
+// third parameter: complex (float2) LDS exchanges; plan_uses_cx() must agree
+#define SM_STATIC_PLANS(X)                 \
+    X(SPlan<1024, 64, false, 4, 32, 32>)       \
+    X(SPlan<2048, 64, false, 4, 16, 16, 8>)    \
+    X(SPlan<4096, 128, false, 4, 16, 16, 16>)  \
+    X(SPlan<8192, SM_T8192, false, SM_W8192, SM_R8192>)  \
+    X(SPlan<16384, 512, false, 4, 32, 32, 16>)\
+    X(SPlan<14336, 512, false, 4, 16, 16, 8, 7>) \
+    X(SPlan<28672, 1024, false, 4, 16, 16, 16, 7>)
+
+// measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
+// 1.6x slower than split exchanges, so no plan uses it for now
+inline bool plan_uses_cx(int N) { (void)N; return false; }
+
+template <class PL> inline void plan_from_static(int N, int& T, std::vector<int>& radices, bool& found) {
+    if (!found && PL::N == N) {
+        T = PL::T; radices.clear();
+        for (int i = 0; i < PL::npass; ++i) radices.push_back(PL::radix(i));
+        found = true;
+    }
+}
+inline bool plan_shape_static(int N, int& T, std::vector<int>& radices) {
+    bool found = false;
+#define SM_PLAN_FROM(...) plan_from_static<__VA_ARGS__>(N, T, radices, found);
+    SM_STATIC_PLANS(SM_PLAN_FROM)
+#undef SM_PLAN_FROM
+    return found;
+}
 
 template <class PL>
 inline bool plan_matches(const FftPlanDev& pl) {
-    if (pl.N != PL::N || pl.T != PL::T || pl.npass != PL::npass || pl.lds_floats != PL::lds_floats) return false;
+    if (pl.N != PL::N || pl.T != PL::T || pl.npass != PL::npass || pl.lds_floats != PL::lds_floats || (pl.cx != 0) != PL::cx) return false;
     for (int i = 0; i < PL::npass; ++i)
         if (pl.radix[i] != PL::radix(i)) return false;
     return true;
@@ -100,8 +128,10 @@ inline bool plan_radices(int N, int T, std::vector<int>& out) {
     return true;
 }
 
+
 inline bool plan_shape(int N, int& T, std::vector<int>& radices) {
     if (N < 1 || N > EMAX * 1024) return false;
+    if (plan_shape_static(N, T, radices)) return true;
     int t0 = ((N + EMAX - 1) / EMAX + 63) / 64 * 64;
     if (t0 < 64) t0 = 64;
     for (T = t0; T <= 1024; T += 64)
@@ -154,7 +184,9 @@ class Pipeline {
                 hp.ok = true;
                 hp.dev.N = N; hp.dev.T = T; hp.dev.npass = (int)rad.size();
                 for (int i = 0; i < MAX_PASSES; ++i) hp.dev.radix[i] = i < (int)rad.size() ? rad[i] : 1;
-                hp.dev.lds_floats = (int)round_up((size_t)lpad(N) + 1, 32);
+                hp.dev.cx = plan_uses_cx(N) ? 1 : 0;
+                hp.dev.lds_floats = hp.dev.cx ? (int)round_up((size_t)2 * (N + (N >> 4) + 1), 32)
+                                              : (int)round_up((size_t)lpad(N) + 1, 32);
                 std::vector<cf2> tw(N);
                 for (int j = 0; j < N; ++j) {
                     const double ang = -2.0 * M_PI * (double)j / (double)N;

@@ -61,7 +61,7 @@ struct DeviceExec {
 };
 
 template <class K>
-__global__ void __launch_bounds__(1024) sm_kernel(const typename K::Params p) {
+__global__ void __launch_bounds__(1024, K::waves) sm_kernel(const typename K::Params p) {
     DeviceExec ex;
     K::run(ex, p);
 }

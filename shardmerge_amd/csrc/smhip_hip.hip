@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,7 @@ struct HipBackend {
     hipError_t first_err = hipSuccess;
     std::string err_msg;
     bool profiling = false;
+    bool trace_launches = getenv("SMHIP_TRACE_LAUNCHES") != nullptr;
     std::vector<ProfEntry> prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -88,6 +90,7 @@ struct HipBackend {
             for (auto& q : prof) if (q.name == K::name()) e = &q;
             if (!e) { prof.push_back(ProfEntry{K::name(), 0, 0.0}); e = &prof.back(); }
             e->launches++; e->ms += ms;
+            if (trace_launches) fprintf(stderr, "[smhip] %-20s grid %6d block %4d lds %6zu  %9.1f us\n", K::name(), grid, block, lds_bytes, ms * 1e3);
         }
     }
     void profile_enable(bool on) { profiling = on; }

@@ -104,3 +104,19 @@ def test_heavy_ties(engine):
     total, resid = pc.spectral_residual(out, ref, drop=64)
     assert abs(rep.cutoff_threshold - tr.cutoff_threshold) <= 1e-5 * max(tr.cutoff_threshold, 1e-6)
     assert resid < 1e-4
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 14336, 28672, 7168, 3072, 5120, 1536])
+def test_static_and_dynamic_plan_lengths(engine, n):
+    """Every straight-line (static plan) length and a few run-time planned ones, as a
+    row transform (2 x n) and as a column transform (n x 2)."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(n)
+    for shape in [(2, n), (n, 2)]:
+        x = torch.randn(*shape, generator=g)
+        f = engine.fft_transform(x)
+        assert so.rel_err(torch.view_as_real(f), torch.view_as_real(so.fft_transform(x))) < TOL_FFT
+        assert so.rel_err(engine.ifft_transform(f), x) < TOL_FFT
+
+
+TOL_FFT = 3e-6
