@@ -1,0 +1,142 @@
+"""Output writer: merged tensors go into safetensors shards that mirror the base
+model's layout.
+
+Same contract as the reference's ModelWriter (shard/writer.py:60-180): the
+output directory gets the base model's ``model.safetensors.index.json``, shard
+files named like the base's, tensors ordered by ``layer_order``, a resume scan
+of shards that already exist and a completeness check in ``finalize``.  One
+difference in mechanism: the reference re-reads and re-writes the
+whole shard for every tensor (O(T^2) bytes); here a shard's tensors are buffered
+and the file is written once when the shard is complete (or at ``finalize`` /
+``flush`` for a partial shard), which keeps resume working at shard granularity.
+"""
+from __future__ import annotations
+
+import json
+import logging
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, Generator, List, Set, Tuple
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import save_file
+
+from .constants import INPUT_LAYER, OUTPUT_LAYER
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class ShardLayer:
+    layer_order_idx: int
+    shard_name: str
+    layer_name: str
+    written: bool
+
+    @property
+    def layer_number(self) -> int:
+        """-1 for the embedding, -2 for final norm / lm_head, N for model.layers.N.*;
+        anything else is an error (reference writer.py:39-57)."""
+        name = self.layer_name
+        if name.startswith("model.embed_tokens.weight"):
+            return INPUT_LAYER
+        if name.startswith("model.norm.weight") or name.startswith("lm_head.weight"):
+            return OUTPUT_LAYER
+        if name.startswith("model.layers."):
+            field_ = name.split(".")[2]
+            number = int(field_)
+            if str(number) == field_:
+                return number
+        raise ValueError(f"Unknown layer name: {name}")
+
+
+@dataclass
+class ModelWriter:
+    base_index: dict
+    output_path: Path
+    layer_order: List[str]
+    output_astype: torch.dtype
+    written_shard_layers: Set[Tuple[str, str]] = field(default_factory=set)
+    shard_to_tensors: Dict[str, Set[str]] = field(default_factory=dict)
+
+    def __post_init__(self):
+        self.output_path = Path(self.output_path)
+        self.output_path.mkdir(parents=True, exist_ok=True)
+        self.index_path = self.output_path / "model.safetensors.index.json"
+        if self.index_path.exists():
+            logger.info(f"Index already exists: {self.index_path}")
+            with open(self.index_path) as fh:
+                self.base_index = json.load(fh)
+        else:
+            with open(self.index_path, "w") as fh:
+                json.dump(self.base_index, fh, indent=2)
+        self.shard_to_tensors = {}
+        for tensor_name, shard_name in self.base_index["weight_map"].items():
+            self.shard_to_tensors.setdefault(shard_name, set()).add(tensor_name)
+        self._rank = {name: i for i, name in enumerate(self.layer_order)}
+        self._pending: Dict[str, Dict[str, torch.Tensor]] = {}
+        self._check_existing_shards()
+
+    # -- resume ---------------------------------------------------------------------
+    def _check_existing_shards(self):
+        for shard_name, expected in self.shard_to_tensors.items():
+            path = self.output_path / shard_name
+            if not path.exists():
+                continue
+            with safe_open(str(path), framework="pt") as fh:
+                for name in fh.keys():
+                    if name not in expected:
+                        raise ValueError(f"Tensor {name} found in {path} but not in base model")
+                    self.written_shard_layers.add((shard_name, name))
+
+    # -- writing ----------------------------------------------------------------------
+    def add_tensor(self, layer_name: str, tensor: torch.Tensor):
+        shard_name = self.base_index["weight_map"][layer_name]
+        if (shard_name, layer_name) in self.written_shard_layers:
+            logger.info(f"Skipping {layer_name} as it's already in written shard {shard_name}")
+            return
+        # the device -> host copy and the cast happen here, as in writer.py:133
+        self._pending.setdefault(shard_name, {})[layer_name] = tensor.detach().to("cpu").to(self.output_astype).contiguous()
+        have = {n for (s, n) in self.written_shard_layers if s == shard_name} | set(self._pending[shard_name])
+        if have >= self.shard_to_tensors[shard_name]:
+            self.flush(shard_name)
+
+    def flush(self, shard_name: str = None):
+        """Write buffered tensors (of one shard, or of all) to disk."""
+        for name in ([shard_name] if shard_name else list(self._pending)):
+            fresh = self._pending.pop(name, None)
+            if not fresh:
+                continue
+            path = self.output_path / name
+            merged: Dict[str, torch.Tensor] = {}
+            if path.exists():                       # partial shard from an earlier run
+                with safe_open(str(path), framework="pt") as fh:
+                    for k in fh.keys():
+                        merged[k] = fh.get_tensor(k)
+            merged.update(fresh)
+            ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
+            save_file(ordered, str(path), metadata={"format": "pt"})
+            for k in fresh:
+                self.written_shard_layers.add((name, k))
+            logger.info(f"Wrote {len(fresh)} tensor(s) to shard {name}")
+
+    def finalize(self):
+        self.flush()
+        missing = [(s, n) for s, names in self.shard_to_tensors.items() for n in names
+                   if (s, n) not in self.written_shard_layers]
+        if missing:
+            logger.error(f"Failed to write all layers. Missing: {missing}")
+            raise RuntimeError(f"Incomplete model output: missing {len(missing)} layers")
+
+    # -- iteration ----------------------------------------------------------------------
+    def shard_layers(self) -> Generator[List[ShardLayer], None, None]:
+        """Shards in file-name order; inside a shard, tensors in layer_order order."""
+        for shard_name in sorted(self.shard_to_tensors):
+            names = sorted(self.shard_to_tensors[shard_name], key=lambda n: self.layer_order.index(n))
+            group = []
+            for name in names:
+                sl = ShardLayer(self.layer_order.index(name), shard_name, name, (shard_name, name) in self.written_shard_layers)
+                sl.layer_number            # raises on unknown names, as the reference does while iterating
+                group.append(sl)
+            yield group

@@ -1,0 +1,30 @@
+"""Worker of tests/test_distributed_gloo.py: one rank of a gloo (CPU) job that runs the
+partitioned merge with the CPU work-group emulator as its device."""
+import asyncio
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+
+import torch  # noqa: E402
+
+from shardmerge_amd import distributed  # noqa: E402
+from shardmerge_amd.config import MergeConfig  # noqa: E402
+from shardmerge_amd.index import LocalModelIndex  # noqa: E402
+from tests.emul.loader import emul_engine  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(1)
+    cfg = MergeConfig.from_yaml(sys.argv[1])
+    distributed.ENGINE_FACTORY = emul_engine
+    idx = LocalModelIndex(cfg.storage_path)
+    asyncio.run(distributed.run_partitioned_merge(cfg, idx, "cpu"))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
