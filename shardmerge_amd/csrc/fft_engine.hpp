@@ -182,11 +182,55 @@ struct DftOdd {
         });
     }
 };
+// multiply by W28^E (compile-time exponent)
+template <int E>
+SM_HD void mul_w28(float& r, float& i) {
+    constexpr int e = ((E % 28) + 28) % 28;
+    if constexpr (e == 0) {
+    } else if constexpr (e == 7) { float t = r; r = i; i = -t;            // * (-i)
+    } else if constexpr (e == 14) { r = -r; i = -i;
+    } else if constexpr (e == 21) { float t = r; r = -i; i = t;           // * (+i)
+    } else {
+        constexpr float c = W28_RE[e];
+        constexpr float s = W28_IM[e];
+        float t = r * c - i * s;
+        i = r * s + i * c;
+        r = t;
+    }
+}
+
 template <> struct Dft<3> { static SM_HD void run(float* re, float* im) { DftOdd<3>::run(re, im); } };
 template <> struct Dft<5> { static SM_HD void run(float* re, float* im) { DftOdd<5>::run(re, im); } };
 template <> struct Dft<7> { static SM_HD void run(float* re, float* im) { DftOdd<7>::run(re, im); } };
 template <> struct Dft<11> { static SM_HD void run(float* re, float* im) { DftOdd<11>::run(re, im); } };
 template <> struct Dft<13> { static SM_HD void run(float* re, float* im) { DftOdd<13>::run(re, im); } };
+
+// 28 = 4 x 7 (the 7 * 2^k lengths of Llama / Mixtral MLP tensors: 14336 = 32*16*28)
+template <> struct Dft<28> {
+    static SM_HD void run(float* re, float* im) {
+        constexpr int A = 4, B = 7, N = 28;
+        float yr[N], yi[N];
+        static_for<0, B>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            float tr[A], ti[A];
+            static_for<0, A>([&](auto a_) { constexpr int a = decltype(a_)::value; tr[a] = re[B * a + b]; ti[a] = im[B * a + b]; });
+            Dft<A>::run(tr, ti);
+            static_for<0, A>([&](auto k_) {
+                constexpr int k1 = decltype(k_)::value;
+                float r = tr[k1], i = ti[k1];
+                mul_w28<b * k1>(r, i);
+                yr[k1 * B + b] = r; yi[k1 * B + b] = i;
+            });
+        });
+        static_for<0, A>([&](auto k_) {
+            constexpr int k1 = decltype(k_)::value;
+            float tr[B], ti[B];
+            static_for<0, B>([&](auto b_) { constexpr int b = decltype(b_)::value; tr[b] = yr[k1 * B + b]; ti[b] = yi[k1 * B + b]; });
+            Dft<B>::run(tr, ti);
+            static_for<0, B>([&](auto k2_) { constexpr int k2 = decltype(k2_)::value; re[k1 + A * k2] = tr[k2]; im[k1 + A * k2] = ti[k2]; });
+        });
+    }
+};
 
 // radices the planner may use (keep in sync with plan_fft in smhip_host.cpp)
 #define SM_RADIX_SWITCH(r, ...)                                  \
@@ -201,6 +245,7 @@ template <> struct Dft<13> { static SM_HD void run(float* re, float* im) { DftOd
         case 11: { constexpr int RX = 11; __VA_ARGS__; } break;  \
         case 13: { constexpr int RX = 13; __VA_ARGS__; } break;  \
         case 16: { constexpr int RX = 16; __VA_ARGS__; } break;  \
+        case 28: { constexpr int RX = 28; __VA_ARGS__; } break;  \
         case 32: { constexpr int RX = 32; __VA_ARGS__; } break;  \
         default: break;                                          \
     }
@@ -284,7 +329,9 @@ SM_HD void cmul(float& ar, float& ai, float br, float bi) {
 // multiply x[i] by w^i, i = 1..R-1, w = W_{Ns*R}^k.  Only the powers w^(2^b) are
 // loaded from the table (exact to half an ulp); the others are products of at
 // most three of them, so a radix-16 butterfly costs 4 table loads instead of 15
-// and keeps 16 instead of 30 registers of twiddles alive.
+// and keeps 16 instead of 30 registers of twiddles alive.  (A base-4 digit
+// variant with 12 registers measured slower on MI355X: more multiplies and, in
+// this code, more spills.)
 template <int R>
 SM_HD void apply_twiddles(float* xr, float* xi, const cf2* tw, int kidx) {
     constexpr int LOGR = R <= 2 ? 1 : R <= 4 ? 2 : R <= 8 ? 3 : R <= 16 ? 4 : 5;
@@ -343,89 +390,24 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
 // to scratch memory).
 template <int COMP, class S> SM_HD float* comp_of(S& s) { if constexpr (COMP == 0) return s.xr; else return s.xi; }
 
-// ---- complex-exchange variants ----------------------------------------------
-// LDS holds float2 elements; one ds_write_b64 / ds_read_b64 per element and two
-// barriers per exchange (instead of 2 x b32 and four barriers), at twice the LDS
-// footprint.  Padding: one spare element per 16 (cpad(b + c) = cpad(b) + cpad(c)
-// for b a multiple of 16).
-SM_HD int cpad(int o) { return o + (o >> 4); }
-
-template <int R>
-SM_HD void pass_gather_cx(float* xr, float* xi, const cf2* lds, int N, int T, int t) {
-    constexpr int MB = EMAX / R;
-    const int nb = N / R;
-    if ((nb & 15) == 0) {
-        const int step = nb + (nb >> 4);
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int j = t + m * T;
-            if (j < nb) {
-                const cf2* b = lds + cpad(j);
-#pragma unroll
-                for (int i = 0; i < R; ++i) { const cf2 v = b[i * step]; xr[m * R + i] = v.x; xi[m * R + i] = v.y; }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int j = t + m * T;
-            if (j < nb) {
-#pragma unroll
-                for (int i = 0; i < R; ++i) { const cf2 v = lds[cpad(j + i * nb)]; xr[m * R + i] = v.x; xi[m * R + i] = v.y; }
-            }
-        }
-    }
-}
-
-template <int R>
-SM_HD void pass_scatter_cx(const float* xr, const float* xi, cf2* lds, int N, int Ns, int T, int t) {
-    constexpr int MB = EMAX / R;
-    const int nb = N / R;
-    const bool big = (Ns & 15) == 0;
-    const bool small = Ns < 16 && (16 % Ns) == 0 && ((Ns * R) & 15) == 0;
-    if (big || small) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int j = t + m * T;
-            if (j < nb) {
-                const int k = j % Ns;
-                const int base0 = (j - k) * R;
-                cf2* b = lds + (big ? cpad(base0 + k) : cpad(base0) + k);
-#pragma unroll
-                for (int i = 0; i < R; ++i) { cf2 v = {xr[m * R + i], xi[m * R + i]}; b[i * Ns + ((i * Ns) >> 4)] = v; }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int j = t + m * T;
-            if (j < nb) {
-                const int k = j % Ns;
-                const int base = (j - k) * R + k;
-#pragma unroll
-                for (int i = 0; i < R; ++i) { cf2 v = {xr[m * R + i], xi[m * R + i]}; lds[cpad(base + i * Ns)] = v; }
-            }
-        }
-    }
-}
-
 // ---- plans -------------------------------------------------------------------
 // DynPlan: length, thread count and radix list are run-time values (any
-// supported length; the radix of each pass is dispatched with a switch; split
-// exchanges).  SPlan<N, T, CX, R...>: everything is a compile-time constant, the
-// passes are unrolled into straight-line code and all index arithmetic folds.
+// supported length; the radix of each pass is dispatched with a switch).
+// SPlan<N, T, R...>: everything is a compile-time constant, the passes are
+// unrolled into straight-line code and all index arithmetic folds.  The hot
+// lengths (powers of two up to 16384, 7*2^11, 7*2^12) get an SPlan instantiation.
 struct DynPlan { static constexpr bool is_static = false; static constexpr bool cx = false; static constexpr int waves = 4; };
-// WAVES_: waves per SIMD the kernel is compiled for (__launch_bounds__): 4 -> 128
-// VGPRs, 6 -> 80, 8 -> 64.
+// CX_ (complex float2 exchanges) and WAVES_ (occupancy target) are experiment knobs
+// that measured slower on MI355X; both are ignored by the engine now.
 template <int N_, int T_, bool CX_, int WAVES_, int... RS>
 struct SPlan {
     static constexpr bool is_static = true;
-    static constexpr bool cx = CX_;
+    static constexpr bool cx = false;
     static constexpr int waves = WAVES_;
     static constexpr int N = N_, T = T_, npass = (int)sizeof...(RS);
     static constexpr int radix(int i) { constexpr int r[] = {RS...}; return r[i]; }
     static constexpr int ns(int p) { int v = 1; for (int i = 0; i < p; ++i) v *= radix(i); return v; }
-    static constexpr int lds_floats = CX_ ? ((2 * (N_ + (N_ >> 4) + 1) + 31) / 32) * 32 : ((N_ + (N_ >> 5) + 1 + 31) / 32) * 32;
+    static constexpr int lds_floats = ((N_ + (N_ >> 5) + 1 + 31) / 32) * 32;
     static_assert(ns(npass) == N_, "radices must multiply to N");
 };
 template <class P> SM_HD int plan_N(const FftPlanDev& pl) { if constexpr (P::is_static) return P::N; else return pl.N; }
@@ -433,50 +415,20 @@ template <class P> SM_HD int plan_T(const FftPlanDev& pl) { if constexpr (P::is_
 template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::is_static) return P::lds_floats; else return pl.lds_floats; }
 
 // Run a whole transform for every group of a work-group.
-//   nat_scatter(tid, state, put): calls put(g, n, e) for every loaded value:
-//        register e holds natural-order element n of group g.
-//   fin_gather(tid, state, get): calls get(g, n, e): register e wants natural-order
-//        output X[n] of group g.
-// Both are pure data movement, so the same kernel code serves the split and the
-// complex exchange mode.  State must expose float xr[EREG], xi[EREG].
+//   nat_scatter(tid, state, comp_c): write the loaded, natural-order values of
+//        component comp (0 = re, 1 = im; passed as std::integral_constant) into
+//        LDS (element n of group g at lds + g*lds_floats + lpad(n)).
+//   fin_gather(tid, state, comp_c): read from LDS (natural order X[k]) what the
+//        storer needs of component comp.
+// State must expose float xr[EREG], xi[EREG].
 template <class P, class Ex, class StT, class NatScatter, class FinGather>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
-    if constexpr (P::is_static && P::cx) {
-        cf2* cl = (cf2*)lds;
-        const int LC = LF / 2;
-        ex.each(st, [&](int tid, S& s) {
-            nat_scatter(tid, s, [&](int g, int n, int e) { cf2 v = {s.xr[e], s.xi[e]}; cl[g * LC + cpad(n)] = v; });
-        });
-        ex.sync();
-        ex.each(st, [&](int tid, S& s) { pass_gather_cx<P::radix(0)>(s.xr, s.xi, cl + (tid / T) * LC, N, T, tid % T); });
-        static_for<0, P::npass>([&](auto p_c) {
-            constexpr int p = decltype(p_c)::value;
-            constexpr int r = P::radix(p);
-            constexpr int Ns = P::ns(p);
-            constexpr bool last = (p + 1 == P::npass);
-            ex.each(st, [&](int tid, S& s) { pass_compute<r>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw); });
-            ex.sync();          // everyone has read the previous layout
-            ex.each(st, [&](int tid, S& s) { pass_scatter_cx<r>(s.xr, s.xi, cl + (tid / T) * LC, N, Ns, T, tid % T); });
-            ex.sync();
-            if constexpr (!last) {
-                ex.each(st, [&](int tid, S& s) {
-                    pass_gather_cx<P::radix(last ? p : p + 1)>(s.xr, s.xi, cl + (tid / T) * LC, N, T, tid % T);
-                });
-            } else {
-                ex.each(st, [&](int tid, S& s) {
-                    fin_gather(tid, s, [&](int g, int n, int e) { const cf2 v = cl[g * LC + cpad(n)]; s.xr[e] = v.x; s.xi[e] = v.y; });
-                });
-            }
-        });
-        ex.sync();
-    } else if constexpr (P::is_static) {
+    if constexpr (P::is_static) {
         static_for<0, 2>([&](auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
-            ex.each(st, [&](int tid, S& s) {
-                nat_scatter(tid, s, [&](int g, int n, int e) { lds[g * LF + lpad(n)] = comp_of<comp>(s)[e]; });
-            });
+            ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
             ex.sync();
             ex.each(st, [&](int tid, S& s) {
                 pass_gather<P::radix(0)>(comp_of<comp>(s), lds + (tid / T) * LF, N, T, tid % T);
@@ -500,9 +452,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
                         pass_gather<P::radix(last ? p : p + 1)>(comp_of<comp>(s), lds + (tid / T) * LF, N, T, tid % T);
                     });
                 } else {
-                    ex.each(st, [&](int tid, S& s) {
-                        fin_gather(tid, s, [&](int g, int n, int e) { comp_of<comp>(s)[e] = lds[g * LF + lpad(n)]; });
-                    });
+                    ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
                 }
                 ex.sync();
             });
@@ -511,9 +461,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
         // natural -> first pass layout, one component at a time
         static_for<0, 2>([&](auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
-            ex.each(st, [&](int tid, S& s) {
-                nat_scatter(tid, s, [&](int g, int n, int e) { lds[g * LF + lpad(n)] = comp_of<comp>(s)[e]; });
-            });
+            ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
             ex.sync();
             ex.each(st, [&](int tid, S& s) {
                 const float* l = lds + (tid / T) * LF;
@@ -542,9 +490,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
                         SM_RADIX_SWITCH(rn, pass_gather<RX>(comp_of<comp>(s), l, N, T, tid % T));
                     });
                 } else {
-                    ex.each(st, [&](int tid, S& s) {
-                        fin_gather(tid, s, [&](int g, int n, int e) { comp_of<comp>(s)[e] = lds[g * LF + lpad(n)]; });
-                    });
+                    ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
                 }
                 ex.sync();
             });

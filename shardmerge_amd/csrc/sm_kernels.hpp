@@ -226,35 +226,44 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
     });
 
     wg_fft<P>(ex, st, pl, lds,
-        [&](int tid, FftState& s, auto&& put) {          // natural scatter
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // natural scatter
             const int g = tid / T, t = tid % T;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
             if (p.vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);
                     if (n0 < C) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) put(g, n0 + c, q * 8 + c);
+                        for (int c = 0; c < 8; ++c) l[lpad(n0 + c)] = x[q * 8 + c];
                     }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < EMAX; ++q) {
                     const int n = t + q * T;
-                    if (n < C) put(g, n, q);
+                    if (n < C) l[lpad(n)] = x[q];
                 }
             }
         },
-        [&](int tid, FftState& s, auto&& get) {          // final gather: Z[k] and Z[C-k]
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // final gather: pairs (k, C-k)
             const int g = tid / T, t = tid % T;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 2 + 1; ++u) {
                 const int k = t + u * T;
                 if (k < p.Cb) {
-                    get(g, k, 2 * u);
-                    get(g, (k == 0) ? 0 : C - k, 2 * u + 1);
+                    const int k2 = (k == 0) ? 0 : C - k;
+                    const float v1 = l[lpad(k)], v2 = l[lpad(k2)];
+                    if (comp == 0) { o[2 * u] = 0.5f * (v1 + v2); o[2 * u + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
+                    else           { o[2 * u] = 0.5f * (v1 - v2); o[2 * u + 1] = 0.5f * (v1 + v2); }   // A.im, B.re
+                    // an absent second signal is EXACTLY zero (its sign class matters: sign(0) = 0);
+                    // the split above would leave rounding noise of random sign there
+                    if (!p.b.x) o[2 * u + 1] = 0.f;
                 }
             }
         });
@@ -268,14 +277,8 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         for (int u = 0; u < EMAX / 2 + 1; ++u) {
             const int k = t + u * T;
             if (k < p.Cb) {
-                // Z = FFT(a + i b):  A[k] = (Z[k] + conj Z[C-k]) / 2,  B[k] = (Z[k] - conj Z[C-k]) / (2i)
-                const float zr = s.xr[2 * u], zi = s.xi[2 * u], mr = s.xr[2 * u + 1], mi = s.xi[2 * u + 1];
                 cf4 v;
-                v.x = 0.5f * (zr + mr); v.y = 0.5f * (zi - mi);
-                v.z = 0.5f * (zi + mi); v.w = 0.5f * (mr - zr);
-                // an absent second signal is EXACTLY zero (its sign class matters: sign(0) = 0);
-                // the split above would leave rounding noise of random sign there
-                if (!p.b.x) { v.z = 0.f; v.w = 0.f; }
+                v.x = s.xr[2 * u]; v.y = s.xi[2 * u]; v.z = s.xi[2 * u + 1]; v.w = s.xr[2 * u + 1];
                 dst[k] = v;
             }
         }
@@ -337,31 +340,34 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     });
 
     wg_fft<P>(ex, st, pl, lds,
-        [&](int tid, FftState& s, auto&& put) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            const float* x = comp_of<comp>(s);
             if (ng == 2) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 2; ++q) {
                     const int n = tid + q * 2 * T;
-                    if (n < R) { put(0, n, 2 * q); put(1, n, 2 * q + 1); }
+                    if (n < R) { lds[lpad(n)] = x[2 * q]; lds[LF + lpad(n)] = x[2 * q + 1]; }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < EMAX; ++q) {
                     const int n = tid + q * T;
-                    if (n < R) put(0, n, q);
+                    if (n < R) lds[lpad(n)] = x[q];
                 }
             }
         },
-        [&](int tid, FftState& s, auto&& get) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 4; ++u) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int k1 = 4 * (t + u * T) + c;
-                    if (k1 < R) get(g, k1, 4 * u + c);
+                    if (k1 < R) o[4 * u + c] = l[lpad(k1)];
                 }
             }
         });
@@ -473,27 +479,30 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
     });
 
     wg_fft<P>(ex, st, pl, lds,
-        [&](int tid, FftState& s, auto&& put) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 4; ++u) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int k1 = 4 * (t + u * T) + c;
-                    if (k1 < R) put(g, k1, 4 * u + c);
+                    if (k1 < R) l[lpad(k1)] = x[4 * u + c];
                 }
             }
         },
-        [&](int tid, FftState& s, auto&& get) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            float* o = comp_of<comp>(s);
             // thread handles rows r = tid + q*(S*T); needs every group's value
 #pragma unroll
             for (int q = 0; q < EMAX / S; ++q) {
                 const int r = tid + q * S * T;
                 if (r < R) {
 #pragma unroll
-                    for (int g = 0; g < S; ++g) get(g, r, q * S + g);
+                    for (int g = 0; g < S; ++g) o[q * S + g] = lds[g * LF + lpad(r)];
                 }
             }
         });
@@ -590,35 +599,39 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
     });
 
     wg_fft<P>(ex, st, pl, lds,
-        [&](int tid, FftState& s, auto&& put) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
 #pragma unroll
             for (int u = 0; u < EMAX / 2 + 1; ++u) {
                 const int k = t + u * T;
                 if (k < p.Cb) {
-                    put(g, k, 2 * u);
-                    if (k != 0 && 2 * k != C) put(g, C - k, 2 * u + 1);
+                    l[lpad(k)] = x[2 * u];
+                    if (k != 0 && 2 * k != C) l[lpad(C - k)] = x[2 * u + 1];
                 }
             }
         },
-        [&](int tid, FftState& s, auto&& get) {
-            (void)s;
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
             if (p.vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);
                     if (n0 < C) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) get(g, n0 + c, q * 8 + c);
+                        for (int c = 0; c < 8; ++c) o[q * 8 + c] = l[lpad(n0 + c)];
                     }
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < EMAX; ++q) {
                     const int n = t + q * T;
-                    if (n < C) get(g, n, q);
+                    if (n < C) o[q] = l[lpad(n)];
                 }
             }
         });

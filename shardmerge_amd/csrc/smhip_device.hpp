@@ -60,11 +60,22 @@ struct DeviceExec {
     }
 };
 
+// 1024 threads per work-group at most; the default bound lets the register allocator
+// use up to 128 VGPRs (4 waves per SIMD).  (An explicit second argument of 4 measured
+// slower on MI355X than leaving it out, so it is only passed for other targets.)
+#ifndef SM_LB_EXPLICIT
+template <class K>
+__global__ void __launch_bounds__(1024) sm_kernel(const typename K::Params p) {
+    DeviceExec ex;
+    K::run(ex, p);
+}
+#else
 template <class K>
 __global__ void __launch_bounds__(1024, K::waves) sm_kernel(const typename K::Params p) {
     DeviceExec ex;
     K::run(ex, p);
 }
+#endif
 
 
 // static-plan transform kernels are compiled in separate translation units
