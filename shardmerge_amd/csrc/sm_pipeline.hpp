@@ -302,6 +302,16 @@ class Pipeline {
     }
 
     // ---- stages ------------------------------------------------------------------
+    // chunks per thread such that a streaming kernel runs about `waves` work-groups per
+    // CU in total: the per-work-group fixed costs (LDS histogram zero/flush, staging,
+    // block reductions, atomics) are paid once per resident work-group, not per 8K elements
+    static int pick_chunks(size_t units, int block, int min_chunks, int wgs_per_cu = 5) {
+        const size_t target = (size_t)256 * wgs_per_cu;
+        size_t c = (units + (size_t)block * target - 1) / ((size_t)block * target);
+        if (c < (size_t)min_chunks) c = min_chunks;
+        if (c > 4096) c = 4096;
+        return (int)c;
+    }
     static int stream_grid(size_t units, int block, int chunks) {
         const size_t per = (size_t)block * chunks;
         size_t g = (units + per - 1) / per;
@@ -356,13 +366,13 @@ class Pipeline {
     // (10 bits) is one streaming pass that also compacts the candidates, level 3 (10
     // bits) runs on the candidate list.  With fuse_reduce the level-2 pass also takes
     // the slerp-class sums (then *nparts_out partial rows of 4 doubles sit in d_part()).
-    static constexpr int CAND_GRID = 32;
+    static constexpr int CAND_GRID = 256;
     void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out,
                     bool fuse_reduce = false, int* nparts_out = nullptr) {
         const size_t total = (size_t)g.Cb * g.R;
         HistParams h;
         h.X = X; h.Y = Y; h.R = g.R; h.C = g.Cw; h.Cb = g.Cb; h.vec4 = vec4(g); h.sel = d_sel(0);
-        h.hist = d_hist(); h.chunks = 8; h.only_if = nullptr;
+        h.hist = d_hist(); h.chunks = pick_chunks((total + 3) / 4, 256, 8); h.only_if = nullptr;
         const int hgrid = stream_grid((total + 3) / 4, 256, h.chunks);
         const size_t hlds = (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4;
         const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256) * 4;
@@ -375,7 +385,7 @@ class Pipeline {
         be.memset(d_candctr(), 0, 16, stream);
         Select2Params q;
         q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0); q.hist = d_hist();
-        q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part(); q.chunks = 8;
+        q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part(); q.chunks = pick_chunks((total + 3) / 4, 256, 8);
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
         while ((size_t)(2 * grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
         const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);
@@ -405,7 +415,7 @@ class Pipeline {
         b.reA = plane(g, P_REA); b.reB = plane(g, P_REB); b.reR = plane(g, P_RER);
         b.R = g.R; b.C = g.Cw; b.Cb = g.Cb; b.vec4 = vec4(g);
         b.mode = mode; b.agreement = agreement; b.t = t; b.t_sum = t_sum;
-        b.consts = d_consts(); b.hist = hist ? d_hist() : nullptr; b.chunks = 8;
+        b.consts = d_consts(); b.hist = hist ? d_hist() : nullptr; b.chunks = pick_chunks((total + 3) / 4, 256, 8, 8);
         be.template launch<KBlend>(stream_grid((total + 3) / 4, 256, b.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, b, stream);
     }
 
@@ -417,7 +427,7 @@ class Pipeline {
         const size_t total = (size_t)g.Cb * g.R;
         ReduceParams r;
         r.reA = plane(g, P_REA); r.reB = plane(g, P_REB); r.R = g.R; r.C = g.Cw; r.Cb = g.Cb; r.vec4 = vec4(g);
-        r.thr = have_thr ? d_thr(0) : nullptr; r.chunks = 16;
+        r.thr = have_thr ? d_thr(0) : nullptr; r.chunks = pick_chunks((total + 3) / 4, 256, 16, 8);
         int grid = stream_grid((total + 3) / 4, 256, r.chunks);
         while ((size_t)(grid + fused_parts) * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
         r.partials = d_part() + 4 * (size_t)fused_parts;
