@@ -300,7 +300,10 @@ struct F2Params {
     unsigned long long* hist;               // level-1 histogram (HIST1_BINS) or null
 };
 
-template <class P, class Ex>
+// BINS adjacent bin columns per work-group (2*BINS transforms, 2*BINS*T threads): the
+// row segment a work-group reads is BINS*16 bytes wide, so short columns get full
+// 128-byte segments (BINS = 8) and 8192-long ones 32 bytes.
+template <class P, int BINS, class Ex>
 SM_HD void k_f2(Ex& ex, const F2Params& p) {
     typename Ex::template State<FftState> st;
     ex.init(st);
@@ -310,18 +313,23 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const int LF = plan_lds<P>(pl);
     const int ng = p.nsig;
     const int bid = ex.bid();
-    const int k2 = (ng == 2) ? xcd_remap(bid, 8) : bid / 2;     // 8 bins of 16 B share a 128-B line
+    // 8/BINS work-groups share a 128-byte line of T1 (16 bytes per bin)
+    const int kbase = (ng == 2) ? xcd_remap(bid, 8 / BINS) * BINS : bid / 2;
     const int slot0 = (ng == 2) ? 0 : bid % 2;
-    if (k2 >= p.Cb) return;
-    uint32_t* lhist = (uint32_t*)(lds + ng * LF);
+    if (kbase >= p.Cb) return;
+    const int ngroups = (ng == 2) ? 2 * BINS : 1;
+    const int nthreads = ngroups * T;
+    uint32_t* lhist = (uint32_t*)(lds + ngroups * LF);
 
     ex.each(st, [&](int tid, FftState& s) {
         if (ng == 2) {
+            const int b = tid % BINS, lane = tid / BINS;
+            const int k2 = kbase + b;
 #pragma unroll
             for (int q = 0; q < EMAX / 2; ++q) {
-                const int n = tid + q * 2 * T;
+                const int n = lane + q * 2 * T;
                 cf4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < R) v = p.t1[(size_t)n * p.pitch4 + k2];
+                if (n < R && k2 < p.Cb) v = p.t1[(size_t)n * p.pitch4 + k2];
                 s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
             }
         } else {
@@ -330,13 +338,13 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                 const int n = tid + q * T;
                 float re = 0.f, im = 0.f;
                 if (n < R) {
-                    const cf2* src = (const cf2*)(p.t1 + (size_t)n * p.pitch4 + k2) + slot0;
+                    const cf2* src = (const cf2*)(p.t1 + (size_t)n * p.pitch4 + kbase) + slot0;
                     re = src->x; im = src->y;
                 }
                 s.xr[q] = re; s.xi[q] = im;
             }
         }
-        if (p.hist) for (int b = tid; b < HIST1_BINS; b += ng * T) lhist[b] = 0;
+        if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
     wg_fft<P>(ex, st, pl, lds,
@@ -344,10 +352,12 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
             if (ng == 2) {
+                const int b = tid % BINS, lane = tid / BINS;
+                float* la = lds + (2 * b) * LF;
 #pragma unroll
                 for (int q = 0; q < EMAX / 2; ++q) {
-                    const int n = tid + q * 2 * T;
-                    if (n < R) { lds[lpad(n)] = x[2 * q]; lds[LF + lpad(n)] = x[2 * q + 1]; }
+                    const int n = lane + q * 2 * T;
+                    if (n < R) { la[lpad(n)] = x[2 * q]; la[LF + lpad(n)] = x[2 * q + 1]; }
                 }
             } else {
 #pragma unroll
@@ -374,7 +384,9 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
 
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
-        const int slot = slot0 + g;
+        const int slot = (ng == 2) ? (g & 1) : slot0;
+        const int k2 = kbase + ((ng == 2) ? (g >> 1) : 0);
+        if (k2 >= p.Cb) return;
         const bool role_a = (slot ^ p.swap) == 0;
         const float sc = p.scale[slot];
         const uint32_t w = (uint32_t)bin_weight(k2, p.C);
@@ -413,13 +425,30 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     if (p.hist) {
         ex.sync();
         ex.each(st, [&](int tid, FftState&) {
-            for (int b = tid; b < HIST1_BINS; b += ng * T) {
-                const uint32_t v = lhist[b];
-                if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+            for (int h = tid; h < HIST1_BINS; h += nthreads) {
+                const uint32_t v = lhist[h];
+                if (v) ex.global_atomic_add(&p.hist[h], (unsigned long long)v);
             }
         });
     }
 }
+
+// bins per work-group of the column passes for a plan with T threads per transform
+// (measured on MI355X: 1024-thread work-groups lose more than their wider row segments
+//  gain - 8192^2: F2 382 -> 415 us, I1 164 -> 203 us - so the target is 512 threads)
+#ifndef SM_COL_THREADS
+#define SM_COL_THREADS 512
+#endif
+constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
+// the inverse column pass measured fastest with two bins per work-group at every length
+constexpr int i1_bins_for(int T) { return 2 * T <= 1024 ? 2 : 1; }
+#ifdef SM_NARROW_COLUMNS
+template <class P> constexpr int f2_bins() { return 1; }
+template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return P::T <= 512 ? 2 : 1; else return 2; }
+#else
+template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T); else return 1; }
+template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return i1_bins_for(P::T); else return 2; }
+#endif
 
 // =====================================================================
 // I1: inverse column pass
@@ -513,11 +542,16 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
             const int r = tid + q * S * T;
             if (r < R) {
                 cf2* dst = p.G + (size_t)r * p.pitchG + (size_t)bid * S;
-                if constexpr (S == 2) {
-                    // swap trick: true (re, im) = (xi, xr); pitchG is even, so the
-                    // pad column absorbs the second bin of the last work-group
-                    cf4 v = {s.xi[2 * q], s.xr[2 * q], s.xi[2 * q + 1], s.xr[2 * q + 1]};
-                    *(cf4*)dst = v;
+                if constexpr (S % 2 == 0) {
+                    // swap trick: true (re, im) = (xi, xr); two bins per 16-byte store (pitchG is
+                    // even and padded, so the pad columns absorb the tail of the last work-group)
+#pragma unroll
+                    for (int g = 0; g < S; g += 2) {
+                        if (bid * S + g < p.pitchG) {
+                            cf4 v = {s.xi[q * S + g], s.xr[q * S + g], s.xi[q * S + g + 1], s.xr[q * S + g + 1]};
+                            *(cf4*)(dst + g) = v;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int g = 0; g < S; ++g) {

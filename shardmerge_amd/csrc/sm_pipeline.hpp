@@ -33,9 +33,9 @@ namespace smhip {
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
 SM_FFT_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1<P>(ex, p))
-SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", k_f2<P>(ex, p))
+SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>()>(ex, p)))
 SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)))
-SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, 2>(ex, p)))
+SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)))
 SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p))
 
 // lengths that get straight-line kernels; must agree with plan_shape() below
@@ -287,6 +287,21 @@ class Pipeline {
     float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
     enum { P_REA = 0, P_IMA = 1, P_REB = 2, P_RER = 3 };
 
+    static bool is_static_plan(const FftPlanDev& pl) {
+        bool found = false;
+#define SM_IS_PLAN(...) if (plan_matches<__VA_ARGS__>(pl)) found = true;
+        SM_STATIC_PLANS(SM_IS_PLAN)
+#undef SM_IS_PLAN
+        return found;
+    }
+#ifdef SM_NARROW_COLUMNS
+    static int f2_bins_host(const FftPlanDev&) { return 1; }
+    static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= 1024 ? 2 : 1; }
+#else
+    static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
+    static int i1_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? i1_bins_for(pl.T) : (2 * pl.T <= 1024 ? 2 : 1); }
+#endif
+
     // launch the static-plan instantiation of a transform kernel when one matches
     template <template <class> class KT, class Params>
     void launch_fft(const FftPlanDev& pl, int grid, int block, size_t lds, const Params& p) {
@@ -355,9 +370,11 @@ class Pipeline {
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
         p.hist = hist ? d_hist() : nullptr;
-        const int grid = p.nsig == 2 ? (int)round_up((size_t)p.Cb, 64) : p.Cb * 2;
-        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nsig * p.plan.lds_floats + HIST1_BINS) * 4;
-        launch_fft<KF2>(p.plan, grid, p.nsig * p.plan.T, lds, p);
+        const int bins = p.nsig == 2 ? f2_bins_host(p.plan) : 1;
+        const int ngroups = p.nsig == 2 ? 2 * bins : 1;
+        const int grid = p.nsig == 2 ? (int)round_up((size_t)(p.Cb + bins - 1) / bins, 64) : p.Cb * 2;
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)ngroups * p.plan.lds_floats + HIST1_BINS) * 4;
+        launch_fft<KF2>(p.plan, grid, ngroups * p.plan.T, lds, p);
         return SMHIP_OK;
     }
 
@@ -450,11 +467,11 @@ class Pipeline {
         if (rc) return rc;
         const int Cb = g.C / 2 + 1;
         a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.R = g.R; a.Cb = Cb;
-        a.s = (2 * a.plan.T <= 1024) ? 2 : 1;
+        a.s = i1_bins_host(a.plan);
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
         const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
-        if (a.s == 2) launch_fft<KI1x2>(a.plan, grid1, 2 * a.plan.T, lds1, a);
+        if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
         else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
 
         I2Params b;
