@@ -177,13 +177,16 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
     const int T = plan_T<P>(pl), C = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
     const int bid = ex.bid();
+    // static plans are launched only when the 16-byte vector path applies (host checks),
+    // so the element-wise path is not even compiled into them
+    const bool vec = P::is_static ? true : (p.vec != 0);
 
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
         const int row = bid * p.nb + g;
         const bool valid = row < p.R;
         double sa = 0.0, sb = 0.0;
-        if (p.vec) {
+        if (vec) {
 #pragma unroll
             for (int q = 0; q < EMAX / 8; ++q) {
                 const int n0 = 8 * (t + q * T);
@@ -231,7 +234,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             const int g = tid / T, t = tid % T;
             float* l = lds + g * LF;
             const float* x = comp_of<comp>(s);
-            if (p.vec) {
+            if (vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);
@@ -609,6 +612,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
     const int T = plan_T<P>(pl), C = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
     const int bid = ex.bid();
+    const bool vec = P::is_static ? true : (p.vec != 0);      // see k_f1
 
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
@@ -652,7 +656,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
             const int g = tid / T, t = tid % T;
             const float* l = lds + g * LF;
             float* o = comp_of<comp>(s);
-            if (p.vec) {
+            if (vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);
@@ -680,7 +684,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
             const int row = r0 + h;
             if (row >= p.R) return;
             const float* x = comp_of<1 - h>(s);
-            if (p.vec) {
+            if (vec) {
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);

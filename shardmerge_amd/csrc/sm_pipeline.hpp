@@ -304,8 +304,8 @@ class Pipeline {
 
     // launch the static-plan instantiation of a transform kernel when one matches
     template <template <class> class KT, class Params>
-    void launch_fft(const FftPlanDev& pl, int grid, int block, size_t lds, const Params& p) {
-        bool done = false;
+    void launch_fft(const FftPlanDev& pl, int grid, int block, size_t lds, const Params& p, bool allow_static = true) {
+        bool done = !allow_static;
 #define SM_TRY_PLAN(...)                                                     \
         if (!done && plan_matches<__VA_ARGS__>(pl)) {                        \
             be.template launch<KT<__VA_ARGS__>>(grid, block, lds, p, stream);\
@@ -313,7 +313,7 @@ class Pipeline {
         }
         SM_STATIC_PLANS(SM_TRY_PLAN)
 #undef SM_TRY_PLAN
-        if (!done) be.template launch<KT<DynPlan>>(grid, block, lds, p, stream);
+        if (!done || !allow_static) be.template launch<KT<DynPlan>>(grid, block, lds, p, stream);
     }
 
     // ---- stages ------------------------------------------------------------------
@@ -348,7 +348,7 @@ class Pipeline {
         const int grid = (g.R + p.nb - 1) / p.nb;
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
-        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p);
+        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
         grid_out = grid;
         return SMHIP_OK;
     }
@@ -486,7 +486,7 @@ class Pipeline {
         const int pairs = (g.R + 1) / 2;
         const int grid2 = (pairs + b.nb - 1) / b.nb;
         const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
-        launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b);
+        launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
         return SMHIP_OK;
     }
 

@@ -120,3 +120,18 @@ def test_static_and_dynamic_plan_lengths(engine, n):
 
 
 TOL_FFT = 3e-6
+
+
+def test_misaligned_inputs_take_the_elementwise_path(engine):
+    """Static-plan lengths assume 16-byte aligned rows; an unaligned view must fall back
+    to the run-time kernel and give the same answer."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(9)
+    big = (torch.randn(3 + 64 * 1024, generator=g) * 0.01).to(torch.bfloat16)
+    base = big[3:3 + 32 * 1024].view(32, 1024)              # 6-byte offset: not 16-byte aligned
+    ft0 = (base.float() + torch.randn(32, 1024, generator=g) * 0.002).to(torch.bfloat16)
+    ft1 = (base.float() + torch.randn(32, 1024, generator=g) * 0.003).to(torch.bfloat16)
+    out_u, rep_u = engine.merge_layer([ft0, ft1], [base, base], [0.3, 0.5], base)
+    out_a, rep_a = engine.merge_layer([ft0, ft1], [base.clone(), base.clone()], [0.3, 0.5], base.clone())
+    assert rep_u.branches == rep_a.branches == ["slerp"]
+    assert torch.equal(out_u, out_a)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs into per-kernel HBM traffic.
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+
+Units and corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters
+are in KiB... (rocprofv3 reports FETCH_SIZE/WRITE_SIZE in kilobytes); on gfx950
+FETCH_SIZE tallies 128-byte requests at 64 bytes, so it reads exactly half of a wide
+coalesced read stream and is doubled here; WRITE_SIZE is taken as is.  Both passes are
+separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def load(d, counter):
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    per = collections.defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(files[-1])):
+        if r["Counter_Name"] != counter:
+            continue
+        m = re.search(r"smhip::(K\w+)", r["Kernel_Name"])
+        if not m:
+            continue
+        per[m.group(1)][0] += float(r["Counter_Value"])
+        per[m.group(1)][1].add(r["Dispatch_Id"])
+    return {k: (v[0], len(v[1])) for k, v in per.items()}
+
+
+NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI1x2": "i1_cols_inv", "KI2": "i2_rows_inv",
+         "KSelect2": "select_lvl2", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (0.0, 0))
+        w, nw = write.get(k, (0.0, 0))
+        n = max(nf, nw, 1)
+        name = NAMES.get(k, k)
+        rec = out.setdefault(name, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
+        rec["launches"] += n
+        rec["fetch_bytes"] += 2.0 * f * 1024.0        # gfx950: FETCH_SIZE reads half of a wide stream
+        rec["write_bytes"] += w * 1024.0
+    for rec in out.values():
+        rec["hbm_bytes_per_launch"] = (rec["fetch_bytes"] + rec["write_bytes"]) / rec["launches"]
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
+        print(f"{k:20s} launches {v['launches']:5d}  fetch {v['fetch_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB  per launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
