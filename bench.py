@@ -67,7 +67,8 @@ KERNEL_ALG_BYTES = {
     "i2_rows_inv": 8.0,      # read 4n + base 2n + write bf16 2n
     "blend": 6.0,
     "slerp_reduce": 4.0,
-    "select_hist": 3.0,      # 4n on (Re a, Re b), 2n on Re R: two launches of each per pair
+    "select_lvl2": 3.0,      # 4n on (Re a, Re b) + 2n on Re R: two launches per pair, 3n on average
+    "select_hist": 3.0,
     "combine": 6.0,
 }
 
@@ -146,7 +147,7 @@ def main():
     ap.add_argument("--workload", default="llama3-8b")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--k", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1, help="tensors merged concurrently (one engine/stream/workspace each)")
+    ap.add_argument("--streams", type=int, default=4, help="tensors merged concurrently (one engine/stream/workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -227,6 +228,8 @@ def main():
     }
 
     if rank == 0 and not args.no_profile:
+        # per-kernel device time: HIP events around every launch on the launch stream
+        # (library profiling mode), one extra pass, single stream
         engine.ctx.profile(True)
         engine.ctx.profile_reset()
         run_step(engines[:1], layers, k)
@@ -234,27 +237,30 @@ def main():
         table = engine.ctx.profile_table()
         engine.ctx.profile(False)
         tot_ms = sum(ms for _, ms in table.values())
-        kern = {name: {"launches": n, "total_ms": ms, "share": ms / tot_ms if tot_ms else 0} for name, (n, ms) in table.items()}
+        kern = {name: {"launches": n, "total_ms": round(ms, 3), "share": round(ms / tot_ms, 4) if tot_ms else 0}
+                for name, (n, ms) in table.items()}
         dom = max(table.items(), key=lambda kv: kv[1][1])[0]
-        n_fft = sum(r * c for r, c in shapes if True)
-        # launches of the dominant kernel cover every tensor once per pair merge (K-1 pairs)
-        per_elem = KERNEL_ALG_BYTES.get(dom, 0.0)
+        # algorithmic bytes of the dominant kernel over the step: per-element bytes of one
+        # launch (SURVEY 8d / DESIGN.md 5) x elements of every tensor it ran on (K-1 pair
+        # merges per tensor; the selection pass runs once on 2 planes and once on 1: 4n + 2n)
         pairs = max(k - 1, 1)
-        launches_per_tensor = {"select_hist": 4}.get(dom, 1)
-        alg = per_elem * n_fft * pairs * launches_per_tensor
-        dom_s = table[dom][1] / 1e3
+        n_2d = sum(r * c for r, c in shapes)
+        per_elem = KERNEL_ALG_BYTES.get(dom, 0.0)
+        alg = per_elem * n_2d * pairs * (2 if dom == "select_lvl2" else 1)
+        launches, dom_ms = table[dom]
         traffic = None
         tf = REPO / "profiles" / "traffic_latest.json"
         if tf.exists():
             try:
-                traffic = json.load(open(tf)).get(dom)
+                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg / dom_s / 1e9, "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": alg / dom_s / HBM_PEAK, "traffic": traffic,
-                              "alg_bytes_per_elem": per_elem, "avg_launch_ms": table[dom][1] / table[dom][0]}
+        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": alg / (dom_ms / 1e3) / HBM_PEAK, "traffic": traffic,
+                              "alg_bytes_per_launch": alg / launches, "avg_launch_ms": dom_ms / launches,
+                              "alg_bytes_per_elem": per_elem}
         result["kernels"] = kern
-        result["device_ms_profiled_step"] = tot_ms
+        result["device_ms_profiled_step"] = round(tot_ms, 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(k)
     if rank == 0:

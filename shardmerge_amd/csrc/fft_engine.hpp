@@ -370,7 +370,7 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
         if (j < nb) {
             if (Ns > 1) {
                 const int k = j % Ns;
-                if constexpr (R == 2 || R == 4 || R == 8 || R == 16 || R == 32) {
+                if constexpr (R <= 32 && R != 28) {        // every radix a plan uses with twiddles
                     apply_twiddles<R>(xr + m * R, xi + m * R, tw, k * tstep);
                 } else {
 #pragma unroll

@@ -144,6 +144,8 @@ SM_HD uint32_t weight_at(const WeightRanges& w, size_t i) {
     return (w.full || i < w.hi0 || (i >= w.loN && i < w.hiN)) ? 1u : 2u;
 }
 
+struct EmptyStateF { double red[2]; };
+
 struct FftState {
     float xr[EREG];
     float xi[EREG];
@@ -436,6 +438,44 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     }
 }
 
+// R == 1 (1-D tensors): the column transform is the identity, so the column passes are
+// plain element-wise kernels (a 2049-work-group launch of the transform kernel for a
+// 4096-element layernorm weight cost 230 us)
+template <class Ex>
+SM_HD void k_f2_r1(Ex& ex, const F2Params& p) {
+    typename Ex::template State<EmptyStateF> st;
+    ex.init(st);
+    uint32_t* lhist = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    if (p.hist) {
+        ex.each(st, [&](int tid, EmptyStateF&) { for (int h = tid; h < HIST1_BINS; h += nt) lhist[h] = 0; });
+        ex.sync();
+    }
+    ex.each(st, [&](int tid, EmptyStateF&) {
+        for (int k2 = ex.bid() * nt + tid; k2 < p.Cb; k2 += ex.nblocks() * nt) {
+            const cf4 v = p.t1[k2];
+            const float in[2][2] = {{v.x, v.y}, {v.z, v.w}};
+            const uint32_t w = (uint32_t)bin_weight(k2, p.C);
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const bool role_a = (slot ^ p.swap) == 0;
+                const float re = in[slot][0] * p.scale[slot], im = in[slot][1] * p.scale[slot];
+                if (role_a) { p.reA[k2] = re; p.imA[k2] = im; } else { p.reB[k2] = re; }
+                if (p.hist) ex.lds_atomic_add(&lhist[(f2u(re) & 0x7fffffffu) >> 20], w);
+            }
+        }
+    });
+    if (p.hist) {
+        ex.sync();
+        ex.each(st, [&](int tid, EmptyStateF&) {
+            for (int h = tid; h < HIST1_BINS; h += nt) {
+                const uint32_t v = lhist[h];
+                if (v) ex.global_atomic_add(&p.hist[h], (unsigned long long)v);
+            }
+        });
+    }
+}
+
 // bins per work-group of the column passes for a plan with T threads per transform
 // (measured on MI355X: 1024-thread work-groups lose more than their wider row segments
 //  gain - 8192^2: F2 382 -> 415 us, I1 164 -> 203 us - so the target is 512 threads)
@@ -444,7 +484,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
 #endif
 constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
 // the inverse column pass measured fastest with two bins per work-group at every length
-constexpr int i1_bins_for(int T) { return 2 * T <= 1024 ? 2 : 1; }
+constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 instead when 2T is too large
 #ifdef SM_NARROW_COLUMNS
 template <class P> constexpr int f2_bins() { return 1; }
 template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return P::T <= 512 ? 2 : 1; else return 2; }
@@ -565,6 +605,22 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
                     }
                 }
             }
+        }
+    });
+}
+
+template <class Ex>
+SM_HD void k_i1_r1(Ex& ex, const I1Params& p) {
+    typename Ex::template State<EmptyStateF> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const float thr = p.cull_thr ? *p.cull_thr : 0.f;
+    ex.each(st, [&](int tid, EmptyStateF&) {
+        for (int k2 = ex.bid() * nt + tid; k2 < p.Cb; k2 += ex.nblocks() * nt) {
+            float re = p.reR[k2];
+            if (fabsf(re) < thr) re = 0.f;
+            cf2 v = {re, p.imA[k2]};
+            p.G[k2] = v;
         }
     });
 }

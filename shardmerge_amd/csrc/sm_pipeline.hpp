@@ -40,6 +40,10 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p))
 
 // lengths that get straight-line kernels; must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
+// largest work-group the column passes may use (A and B / two bins together)
+#ifndef SM_COLS_MAX_THREADS
+#define SM_COLS_MAX_THREADS 1024
+#endif
 // experiment knobs for the 8192-point plan (override with -D on the hipcc line)
 #ifndef SM_T8192
 #define SM_T8192 256
@@ -82,6 +86,8 @@ inline bool plan_matches(const FftPlanDev& pl) {
         if (pl.radix[i] != PL::radix(i)) return false;
     return true;
 }
+SM_KERNEL_TAG(KF2R1, F2Params, "f2_cols_fwd", k_f2_r1(ex, p))
+SM_KERNEL_TAG(KI1R1, I1Params, "i1_cols_inv", k_i1_r1(ex, p))
 SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
 SM_KERNEL_TAG(KSelect2, Select2Params, "select_lvl2", k_select2(ex, p))
@@ -299,7 +305,7 @@ class Pipeline {
     static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= 1024 ? 2 : 1; }
 #else
     static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
-    static int i1_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? i1_bins_for(pl.T) : (2 * pl.T <= 1024 ? 2 : 1); }
+    static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= SM_COLS_MAX_THREADS ? 2 : 1; }
 #endif
 
     // launch the static-plan instantiation of a transform kernel when one matches
@@ -365,8 +371,16 @@ class Pipeline {
         F2Params p;
         int rc = get_plan(g.R, p.plan);
         if (rc) return rc;
+        if (g.R == 1) {
+            p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = 1; p.C = g.C; p.Cb = g.C / 2 + 1; p.nsig = 2;
+            p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
+            p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
+            p.hist = hist ? d_hist() : nullptr;
+            be.template launch<KF2R1>(std::max(1, std::min(64, (p.Cb + 255) / 256)), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, p, stream);
+            return SMHIP_OK;
+        }
         p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
-        p.nsig = (2 * p.plan.T <= 1024) ? 2 : 1;
+        p.nsig = (2 * p.plan.T <= SM_COLS_MAX_THREADS) ? 2 : 1;
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
         p.hist = hist ? d_hist() : nullptr;
@@ -467,12 +481,17 @@ class Pipeline {
         if (rc) return rc;
         const int Cb = g.C / 2 + 1;
         a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.R = g.R; a.Cb = Cb;
+        if (g.R == 1) {
+            a.s = 1; a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
+            be.template launch<KI1R1>(std::max(1, std::min(64, (Cb + 255) / 256)), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        } else {
         a.s = i1_bins_host(a.plan);
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
         const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
         if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
         else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
+        }
 
         I2Params b;
         if ((rc = get_plan(g.C, b.plan))) return rc;
