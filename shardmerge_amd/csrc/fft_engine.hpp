@@ -21,6 +21,13 @@
 #define SM_HD inline
 #endif
 #define SM_CONST static constexpr
+// keep the instruction scheduler from interleaving independent butterflies: one
+// butterfly's temporaries die before the next one's are born (register pressure)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SM_NO_SCHED_BARRIER)
+#define SM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SM_SCHED_FENCE() ((void)0)
+#endif
 
 namespace smhip {
 
@@ -381,6 +388,9 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
                 }
             }
             Dft<R>::run(xr + m * R, xi + m * R);
+#ifdef SM_USE_SCHED_FENCE
+            if (MB > 1) SM_SCHED_FENCE();
+#endif
         }
     }
 }

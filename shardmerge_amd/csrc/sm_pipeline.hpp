@@ -21,22 +21,28 @@ namespace smhip {
     struct Tag {                                                                     \
         using Params = ParamsT;                                                      \
         static constexpr int waves = 4;                                              \
+        static constexpr int max_threads = 1024;                                     \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
 // the four transform kernels exist once per static plan plus once for DynPlan
-#define SM_FFT_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                  \
+template <class P, int GROUPS> constexpr int fft_max_threads() {
+    if constexpr (P::is_static) return (GROUPS * P::T < 256) ? 256 : (GROUPS * P::T > 1024 ? 1024 : GROUPS * P::T);
+    else return 1024;
+}
+#define SM_FFT_KERNEL_TAG(Tag, ParamsT, NAME, CALL, GROUPS, WAVES)                   \
     template <class P> struct Tag {                                                  \
         using Params = ParamsT;                                                      \
-        static constexpr int waves = P::waves;                                       \
+        static constexpr int waves = (WAVES < 4 && P::is_static && fft_max_threads<P, GROUPS>() <= 512) ? WAVES : 4; \
+        static constexpr int max_threads = waves < 4 ? fft_max_threads<P, GROUPS>() : 1024; \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
-SM_FFT_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1<P>(ex, p))
-SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>()>(ex, p)))
-SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)))
-SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)))
-SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p))
+SM_FFT_KERNEL_TAG(KF1, F1Params, "f1_rows_fwd", k_f1<P>(ex, p), 1, 3)
+SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>()>(ex, p)), 2 * f2_bins<P>(), 4)
+SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)), 1, 4)
+SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)), i1_bins<P>(), 4)
+SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
 
 // lengths that get straight-line kernels; must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)

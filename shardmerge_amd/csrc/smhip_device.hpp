@@ -60,23 +60,15 @@ struct DeviceExec {
     }
 };
 
-// 1024 threads per work-group at most; the default bound lets the register allocator
-// use up to 128 VGPRs (4 waves per SIMD).  (An explicit second argument of 4 measured
-// slower on MI355X than leaving it out, so it is only passed for other targets.)
-#ifndef SM_LB_EXPLICIT
+// Each kernel tag states its largest work-group (max_threads) and the waves per SIMD it
+// is compiled for.  Default (1024, 4): at most 128 VGPRs.  The forward row pass is the
+// one kernel that measured faster on MI355X with 3 waves per SIMD (168 VGPRs, no scratch
+// spills, -10..-17 % time); the column passes lose 30 % that way and stay at 4.
 template <class K>
-__global__ void __launch_bounds__(1024) sm_kernel(const typename K::Params p) {
+__global__ void __launch_bounds__(K::max_threads, K::waves) sm_kernel(const typename K::Params p) {
     DeviceExec ex;
     K::run(ex, p);
 }
-#else
-template <class K>
-__global__ void __launch_bounds__(1024, K::waves) sm_kernel(const typename K::Params p) {
-    DeviceExec ex;
-    K::run(ex, p);
-}
-#endif
-
 
 // static-plan transform kernels are compiled in separate translation units
 // (smhip_inst.hip, one per plan) so that the build parallelises
