@@ -319,8 +319,10 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const int ng = p.nsig;
     const int bid = ex.bid();
     // 8/BINS work-groups share a 128-byte line of T1 (16 bytes per bin)
-    const int kbase = (ng == 2) ? xcd_remap(bid, 8 / BINS) * BINS : bid / 2;
-    const int slot0 = (ng == 2) ? 0 : bid % 2;
+    // (one signal per work-group, T = 1024: the 16 work-groups of a line - 8 bins x 2 signals)
+    const int lbid = (ng == 2) ? xcd_remap(bid, 8 / BINS) : xcd_remap(bid, 16);
+    const int kbase = (ng == 2) ? lbid * BINS : lbid / 2;
+    const int slot0 = (ng == 2) ? 0 : lbid % 2;
     if (kbase >= p.Cb) return;
     const int ngroups = (ng == 2) ? 2 * BINS : 1;
     const int nthreads = ngroups * T;
@@ -484,7 +486,11 @@ SM_HD void k_f2_r1(Ex& ex, const F2Params& p) {
 #endif
 constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
 // the inverse column pass measured fastest with two bins per work-group at every length
+#ifndef SM_I1_THREADS
 constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 instead when 2T is too large
+#else
+constexpr int i1_bins_for(int T) { return (SM_I1_THREADS / T) > 2 ? ((SM_I1_THREADS / T) > 16 ? 16 : (SM_I1_THREADS / T)) : 2; }
+#endif
 #ifdef SM_NARROW_COLUMNS
 template <class P> constexpr int f2_bins() { return 1; }
 template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return P::T <= 512 ? 2 : 1; else return 2; }

@@ -311,7 +311,10 @@ class Pipeline {
     static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= 1024 ? 2 : 1; }
 #else
     static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
-    static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= SM_COLS_MAX_THREADS ? 2 : 1; }
+    static int i1_bins_host(const FftPlanDev& pl) {
+        if (2 * pl.T > SM_COLS_MAX_THREADS) return 1;
+        return is_static_plan(pl) ? i1_bins_for(pl.T) : 2;
+    }
 #endif
 
     // launch the static-plan instantiation of a transform kernel when one matches
@@ -392,7 +395,7 @@ class Pipeline {
         p.hist = hist ? d_hist() : nullptr;
         const int bins = p.nsig == 2 ? f2_bins_host(p.plan) : 1;
         const int ngroups = p.nsig == 2 ? 2 * bins : 1;
-        const int grid = p.nsig == 2 ? (int)round_up((size_t)(p.Cb + bins - 1) / bins, 64) : p.Cb * 2;
+        const int grid = p.nsig == 2 ? (int)round_up((size_t)(p.Cb + bins - 1) / bins, 64) : (int)round_up((size_t)p.Cb * 2, 128);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)ngroups * p.plan.lds_floats + HIST1_BINS) * 4;
         launch_fft<KF2>(p.plan, grid, ngroups * p.plan.T, lds, p);
         return SMHIP_OK;

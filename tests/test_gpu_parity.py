@@ -84,6 +84,27 @@ def test_layer_k2_vs_oracle(engine, shape):
     assert so.rel_err(out.cpu().float(), ref.float()) < 1e-3 + 1.5 * shift
 
 
+@pytest.mark.parametrize("shape", [(28672, 16), (16, 28672), (14336, 32), (8, 4096), (16384, 8), (3072, 40)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_long_and_odd_lengths_on_device(engine, shape):
+    """Llama-3-70B / Mixtral lengths (7 * 2^12, 7 * 2^11, the 8 x 4096 router) and run-time
+    planned ones, as transforms and as a K=2 merge against the exact-norm oracle."""
+    rows, cols = shape
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g)
+    f = engine.fft_transform(x).cpu()
+    assert so.rel_err(torch.view_as_real(f), torch.view_as_real(so.fft_transform(x))) < 3e-6
+    assert so.rel_err(engine.ifft_transform(f).cpu(), x) < 3e-6
+    base, fts = so.synthetic_layer(rows, cols, 2, seed=77 + rows)
+    trx = so.LayerTrace()
+    with so.exact_norms():
+        so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
+    assert rep.branches == trx.branches
+    d_total, d_resid = pc.spectral_residual(delta.cpu(), trx.merged_delta)
+    assert d_resid < 2e-5 and d_total < 8.0 / math.sqrt(rows * cols)
+
+
 def test_layer_k3_vs_oracle(engine):
     base, fts = so.synthetic_layer(1024, 1024, 3, seed=5000)
     tr = so.LayerTrace()
