@@ -186,3 +186,33 @@ def test_full_size_scale_equivariance_and_determinism(engine, full_inputs):
     assert info.cutoff_threshold > 0 and info.cull_threshold > info.cutoff_threshold
     assert 0 < info.n_slerp < N_FULL * N_FULL
     assert abs(rep1.merged_delta_norm / rep1.target_norm - 1) < 0.2
+
+
+def test_cli_end_to_end_on_device(tmp_path, golden):
+    """`python -m shard merge CONFIG` (device: cuda) on the tiny on-disk model of G8:
+    files, index, README and tensors against the reference CLI's output."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    from safetensors import safe_open
+    repo = Path(__file__).resolve().parents[1]
+    cfg = gi.write_cli_model(tmp_path, device="cuda")
+    res = subprocess.run([sys.executable, "-m", "shard", "merge", str(cfg), "--device", "cuda"], cwd=str(repo),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out_dir = tmp_path / "merged"
+    want = golden.manifest["cli"]
+    assert sorted(p.name for p in out_dir.iterdir()) == want["files"]
+    assert json.load(open(out_dir / "model.safetensors.index.json")) == want["index"]
+    assert (out_dir / "README.md").read_text() == want["readme"]
+    for shard in gi.CLI_SHARDS:
+        with safe_open(str(out_dir / shard), framework="pt") as f:
+            for k in f.keys():
+                ref = golden.get("g8_cli.safetensors", f"{shard}::{k}")
+                got = f.get_tensor(k)
+                assert got.dtype == ref.dtype and got.shape == ref.shape
+                if "layers" in k:
+                    assert so.rel_err(got.float(), ref.float()) < 2e-3
+                else:
+                    assert torch.equal(got, ref)
