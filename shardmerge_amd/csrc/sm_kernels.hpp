@@ -926,8 +926,10 @@ struct Select2Params {
     const float* X; const float* Y;     // Y may be null
     int R, C, Cb;
     int vec4;
-    const SelState* sel;
-    unsigned long long* hist;           // HIST_LO_BINS
+    SelState* sel;                      // written by work-group 0: level-1 bin and rank inside it
+    const unsigned long long* hist1;    // level-1 histogram (HIST1_BINS), complete
+    unsigned long long rank;            // 0-based rank wanted
+    unsigned long long* hist;           // level-2 histogram (HIST_LO_BINS), accumulated here
     CandLists cand;
     int fuse_reduce;                    // needs Y: X = Re a, Y = Re b
     double* partials;                   // [grid][4] when fuse_reduce
@@ -939,13 +941,24 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
     uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
-    uint32_t* lctl = lh + HIST_LO_BINS;                 // [0] nkeys [1] npairs [2] base keys [3] base pairs
+    uint32_t* lctl = lh + HIST_LO_BINS;                 // [0] nkeys [1] npairs [2] base keys [3] base pairs [4..6] resolve
     uint32_t* lkeys = lctl + 8;
     cf4* lpairs = (cf4*)(lkeys + STAGE_KEYS);
     const int nt = ex.nthreads();
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
-    const uint32_t prefix = p.sel->prefix;
+    // level 1: every work-group resolves it for itself (the staging area doubles as scratch)
+    wg_resolve(ex, st, p.hist1, HIST1_BINS, p.rank, (unsigned long long*)lkeys, lctl + 4);
+    const uint32_t prefix = lctl[4];
+    if (ex.bid() == 0) {
+        ex.each(st, [&](int tid, EmptyState&) {
+            if (tid == 0) {
+                p.sel->prefix = prefix; p.sel->level = 1;
+                p.sel->rank = (unsigned long long)lctl[5] | ((unsigned long long)lctl[6] << 32);
+            }
+        });
+    }
+    ex.sync();
     const WeightRanges wr = weight_ranges(p.R, p.C);
     ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0;
@@ -1007,7 +1020,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             const uint32_t bk = nk ? ex.global_atomic_add_ret_u32(&p.cand.counters[0], nk) : 0u;
             const uint32_t bp = np ? ex.global_atomic_add_ret_u32(&p.cand.counters[1], np) : 0u;
             if (bk + nk > p.cand.cap_keys || bp + np > p.cand.cap_pairs) over = true;
-            if (over) ex.global_atomic_or_u32(&p.cand.counters[2], 1u);
+            if (over) { ex.global_atomic_or_u32(&p.cand.counters[2], 1u); ex.global_atomic_or_u32(&p.cand.counters[3], 1u); }
             lctl[0] = nk; lctl[1] = np; lctl[2] = bk; lctl[3] = bp;
         }
     });
@@ -1032,18 +1045,24 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
 // level 3 on the candidate list (or nothing when the list overflowed)
 struct Select3Params {
     CandLists cand;
-    const SelState* sel;
-    unsigned long long* hist;
+    SelState* sel;                      // in: level-1 prefix/rank; work-group 0 writes the level-2 ones
+    const unsigned long long* hist2;    // level-2 histogram, complete
+    unsigned long long* hist;           // level-3 histogram, accumulated here
 };
 template <class Ex>
 SM_HD void k_select3(Ex& ex, const Select3Params& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
     uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    uint32_t* lres = lh + HIST_LO_BINS;
+    unsigned long long* part = (unsigned long long*)(lres + 8);
     const int nt = ex.nthreads();
-    if (p.cand.counters[2]) return;                    // overflow: the full pass does it
-    const uint32_t n = p.cand.counters[0];
-    const uint32_t prefix = p.sel->prefix;
+    const uint32_t n = p.cand.counters[2] ? 0u : p.cand.counters[0];     // overflow: the caller redoes the layer
+    const uint32_t prefix1 = p.sel->prefix;
+    const unsigned long long rank1 = p.sel->rank;
+    wg_resolve(ex, st, p.hist2, HIST_LO_BINS, rank1, part, lres);
+    const uint32_t prefix = (prefix1 << 10) | lres[0];
+    const unsigned long long rank2 = (unsigned long long)lres[1] | ((unsigned long long)lres[2] << 32);
     ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0; });
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
@@ -1060,6 +1079,13 @@ SM_HD void k_select3(Ex& ex, const Select3Params& p) {
             if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
         }
     });
+    // every work-group has read the level-1 state before any can get here? No: work-group 0
+    // may run ahead, so the level-2 state goes to the SECOND slot (sel + 1)
+    if (ex.bid() == 0) {
+        ex.each(st, [&](int tid, EmptyState&) {
+            if (tid == 0) { p.sel[1].prefix = prefix; p.sel[1].rank = rank2; p.sel[1].level = 2; }
+        });
+    }
 }
 
 // settle the undecided pairs once the cutoff threshold is known
@@ -1091,6 +1117,46 @@ SM_HD void k_reduce_cand(Ex& ex, const ReduceCandParams& p) {
     });
 }
 
+// Work-group-wide resolution of one radix-select level: which bin of `hist` holds the
+// element of 0-based rank `rank`, and its rank inside that bin.  Every thread of a
+// 256-thread work-group takes part; the result lands in res[0] (bin), res[1..2] (new
+// rank, lo/hi).  Consumer kernels run this on the previous level's histogram instead of
+// waiting for a separate single-work-group scan launch.
+template <class Ex, class StT>
+SM_HD void wg_resolve(Ex& ex, StT& st, const unsigned long long* hist, int nbins, unsigned long long rank,
+                      unsigned long long* part, uint32_t* res) {
+    using S = typename StT::value_type;
+    const int nt = ex.nthreads();
+    const int per = (nbins + nt - 1) / nt;
+    ex.each(st, [&](int tid, S&) {
+        unsigned long long s = 0;
+        for (int b = tid * per; b < (tid + 1) * per && b < nbins; ++b) s += hist[b];
+        part[tid] = s;
+        if (tid == 0) { res[0] = 0; res[1] = 0; res[2] = 0; }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, S&) {
+        unsigned long long excl = 0, total = 0;
+        for (int q = 0; q < nt; ++q) { if (q < tid) excl += part[q]; total += part[q]; }
+        if (total == 0) return;
+        unsigned long long r = rank >= total ? total - 1 : rank;
+        if (r >= excl && r < excl + part[tid]) {
+            unsigned long long cum = excl;
+            for (int b = tid * per; b < (tid + 1) * per && b < nbins; ++b) {
+                const unsigned long long h = hist[b];
+                if (r < cum + h) {
+                    res[0] = (uint32_t)b;
+                    const unsigned long long nr = r - cum;
+                    res[1] = (uint32_t)(nr & 0xffffffffull); res[2] = (uint32_t)(nr >> 32);
+                    break;
+                }
+                cum += h;
+            }
+        }
+    });
+    ex.sync();
+}
+
 struct ScanParams {
     unsigned long long* hist;   // consumed and zeroed
     SelState* sel;
@@ -1100,6 +1166,7 @@ struct ScanParams {
     float* value_out;           // optional extra copy of the value
     int init;                   // 1: first level, start from rank_init / empty prefix
     unsigned long long rank_init;
+    unsigned long long* zero_also; int zero_count;   // further histogram words to clear (fast path: all levels)
 };
 
 // single work-group of 256 threads
@@ -1146,6 +1213,7 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) p.hist[b] = 0;
+        if (p.zero_also) for (int b = tid; b < p.zero_count; b += nt) p.zero_also[b] = 0;
     });
 }
 

@@ -175,6 +175,7 @@ class Pipeline {
     std::string err;
     void* stream = nullptr;
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
+    bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
 
     explicit Pipeline(int device) : be(device) {}
     ~Pipeline() {
@@ -272,7 +273,7 @@ class Pipeline {
     }
     // small device block layout
     static constexpr size_t OFF_HIST = 0;                                  // u64[2048]
-    static constexpr size_t OFF_SEL = OFF_HIST + 8 * HIST1_BINS;           // SelState[2]
+    static constexpr size_t OFF_SEL = OFF_HIST + 8 * (HIST1_BINS + 2 * HIST_LO_BINS);   // SelState[2]; hist1 | hist2 | hist3 before it
     static constexpr size_t OFF_CONSTS = OFF_SEL + 2 * sizeof(SelState);   // BlendConsts
     static constexpr size_t OFF_THR = OFF_CONSTS + 256;                    // float thr[4]
     static constexpr size_t OFF_FLAGS = OFF_THR + 64;                      // u32[8]
@@ -282,6 +283,8 @@ class Pipeline {
     static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
     static constexpr size_t SMALL_BYTES = OFF_PART + PART_DOUBLES * 8;
     unsigned long long* d_hist() { return (unsigned long long*)((char*)small_.p + OFF_HIST); }
+    unsigned long long* d_hist2() { return d_hist() + HIST1_BINS; }
+    unsigned long long* d_hist3() { return d_hist2() + HIST_LO_BINS; }
     SelState* d_sel(int i) { return (SelState*)((char*)small_.p + OFF_SEL) + i; }
     BlendConsts* d_consts() { return (BlendConsts*)((char*)small_.p + OFF_CONSTS); }
     float* d_thr(int i) { return (float*)((char*)small_.p + OFF_THR) + i; }
@@ -402,10 +405,12 @@ class Pipeline {
     }
 
     // exact k-th smallest of |X| (and |Y|) with bin multiplicities -> *thr_out.
-    // Level 1 (11 bits) may already sit in d_hist() (fused into F2 / blend); level 2
-    // (10 bits) is one streaming pass that also compacts the candidates, level 3 (10
-    // bits) runs on the candidate list.  With fuse_reduce the level-2 pass also takes
-    // the slerp-class sums (then *nparts_out partial rows of 4 doubles sit in d_part()).
+    // Level 1 (11 bits) may already sit in d_hist() (fused into F2 / blend).  Fast path:
+    // level 2 (10 bits) is one streaming pass that resolves level 1 itself, compacts the
+    // ~1 % candidate keys and (fuse_reduce) takes the slerp-class sums; level 3 runs on the
+    // candidate list and resolves level 2 itself; one single-work-group scan finishes.
+    // A candidate-list overflow sets a sticky flag; the caller then redoes the work with
+    // safe_select = true: three plain histogram passes, one scan after each.
     static constexpr int CAND_GRID = 256;
     void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out,
                     bool fuse_reduce = false, int* nparts_out = nullptr) {
@@ -417,28 +422,37 @@ class Pipeline {
         const size_t hlds = (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4;
         const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256) * 4;
         ScanParams s;
-        s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out;
+        s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out; s.zero_also = nullptr; s.zero_count = 0;
         if (!level1_done) { h.level = 1; be.template launch<KHist>(hgrid, 256, hlds, h, stream); }
-        s.nbins = HIST1_BINS; s.shift = 11; s.final_level = 0; s.init = 1; s.rank_init = rank;
-        be.template launch<KScan>(1, 256, scan_lds, s, stream);
-
-        be.memset(d_candctr(), 0, 16, stream);
+        if (nparts_out) *nparts_out = 0;
+        if (safe_select) {
+            s.nbins = HIST1_BINS; s.shift = 11; s.final_level = 0; s.init = 1; s.rank_init = rank;
+            be.template launch<KScan>(1, 256, scan_lds, s, stream);
+            for (int level = 2; level <= 3; ++level) {
+                h.level = level;
+                be.template launch<KHist>(hgrid, 256, hlds, h, stream);
+                s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = (level == 3); s.init = 0;
+                be.template launch<KScan>(1, 256, scan_lds, s, stream);
+            }
+            return;
+        }
+        be.memset(d_candctr(), 0, 12, stream);             // n_keys, n_pairs, overflow (not the sticky word)
         Select2Params q;
-        q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0); q.hist = d_hist();
-        q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part(); q.chunks = pick_chunks((total + 3) / 4, 256, 8);
+        q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0);
+        q.hist1 = d_hist(); q.rank = rank; q.hist = d_hist2();
+        q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part();
+        q.chunks = pick_chunks((total + 3) / 4, 256, 8);
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
-        while ((size_t)(2 * grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
+        while ((size_t)(grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
         const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);
         be.template launch<KSelect2>(grid2, 256, lds2, q, stream);
-        s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = 0; s.init = 0;
-        be.template launch<KScan>(1, 256, scan_lds, s, stream);
 
         Select3Params t3;
-        t3.cand = q.cand; t3.sel = d_sel(0); t3.hist = d_hist();
-        be.template launch<KSelect3>(CAND_GRID, 256, (LDS_SCRATCH_FLOATS + HIST_LO_BINS) * 4, t3, stream);
-        h.level = 3; h.only_if = d_candctr() + 2;            // full pass only after a list overflow
-        be.template launch<KHist>(hgrid, 256, hlds, h, stream);
-        s.final_level = 1;
+        t3.cand = q.cand; t3.sel = d_sel(0); t3.hist2 = d_hist2(); t3.hist = d_hist3();
+        be.template launch<KSelect3>(CAND_GRID, 256, (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + 2 * 256) * 4, t3, stream);
+
+        s.hist = d_hist3(); s.sel = d_sel(1); s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = 1; s.init = 0;
+        s.zero_also = d_hist(); s.zero_count = HIST1_BINS + HIST_LO_BINS;      // hist1 and hist2 (hist3 is s.hist)
         be.template launch<KScan>(1, 256, scan_lds, s, stream);
 
         if (q.fuse_reduce) {
@@ -460,27 +474,24 @@ class Pipeline {
     }
 
     // masked slerp sums + constants (reference functions.py:36-43 on the slerp class).
-    // fused_parts > 0: the level-2 selection pass already left the sums in d_part()
-    // (valid unless the candidate lists overflowed, in which case the full pass below
-    // - which otherwise exits at once - provides them).
+    // fused_parts > 0: the level-2 selection pass already left the sums in d_part().
     void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts) {
         const size_t total = (size_t)g.Cb * g.R;
-        ReduceParams r;
-        r.reA = plane(g, P_REA); r.reB = plane(g, P_REB); r.R = g.R; r.C = g.Cw; r.Cb = g.Cb; r.vec4 = vec4(g);
-        r.thr = have_thr ? d_thr(0) : nullptr; r.chunks = pick_chunks((total + 3) / 4, 256, 16, 8);
-        int grid = stream_grid((total + 3) / 4, 256, r.chunks);
-        while ((size_t)(grid + fused_parts) * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
-        r.partials = d_part() + 4 * (size_t)fused_parts;
-        r.only_if = fused_parts > 0 ? d_candctr() + 2 : nullptr;
-        be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
         SlerpConstParams c;
+        c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
+        c.thr = have_thr ? d_thr(0) : nullptr; c.t = t; c.out = d_consts();
         if (fused_parts > 0) {
             c.partials = d_part(); c.nparts = fused_parts;
-            c.fallback = r.partials; c.nfallback = grid; c.overflow = d_candctr() + 2;
         } else {
-            c.partials = r.partials; c.nparts = grid; c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
+            ReduceParams r;
+            r.reA = plane(g, P_REA); r.reB = plane(g, P_REB); r.R = g.R; r.C = g.Cw; r.Cb = g.Cb; r.vec4 = vec4(g);
+            r.thr = c.thr; r.chunks = pick_chunks((total + 3) / 4, 256, 16, 8); r.only_if = nullptr;
+            int grid = stream_grid((total + 3) / 4, 256, r.chunks);
+            while ((size_t)grid * 4 > PART_DOUBLES) { r.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, r.chunks); }
+            r.partials = d_part();
+            be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
+            c.partials = r.partials; c.nparts = grid;
         }
-        c.thr = r.thr; c.t = t; c.out = d_consts();
         be.template launch<KSlerpConsts>(1, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
     }
 
@@ -583,10 +594,17 @@ class Pipeline {
     int merge_pair_slerp(const float* v0, const float* v1, int R, int C, double t, double bthr, double t_sum,
                          double cutoff_pct, double cull_pct, float* out, double* n0o, double* n1o, int* branch,
                          smhip_blend_info* info) {
+        return with_select_retry([&] {
+            return merge_pair_slerp_once(v0, v1, R, C, t, bthr, t_sum, cutoff_pct, cull_pct, out, n0o, n1o, branch, info);
+        });
+    }
+    int merge_pair_slerp_once(const float* v0, const float* v1, int R, int C, double t, double bthr, double t_sum,
+                              double cutoff_pct, double cull_pct, float* out, double* n0o, double* n1o, int* branch,
+                              smhip_blend_info* info) {
         const Geo g = geo(R, C);
         int rc = reserve(R, C);
         if (rc) return rc;
-        be.memset(d_flags(), 0, 32, stream);
+        clear_flags();
         SigDesc a{v0, nullptr, DT_F32, 1.f}, b{v1, nullptr, DT_F32, 1.f};
         int grid;
         if ((rc = run_f1(g, a, b, grid))) return rc;
@@ -645,11 +663,31 @@ class Pipeline {
         return SMHIP_OK;
     }
 
-    void clear_flags() { be.memset(d_flags(), 0, 32, stream); }
+    // NaN/Inf flags and, right behind them, the candidate-list counters with their sticky overflow word
+    void clear_flags() { be.memset(d_flags(), 0, 48, stream); overflow_seen_ = false; }
+    // did a candidate list overflow since clear_flags()?  (sticky word, read with a sync)
+    bool select_overflowed() {
+        uint32_t v = 0;
+        be.d2h(&v, d_candctr() + 3, sizeof v, stream);
+        return v != 0;
+    }
+    // Run `body` (a whole API call); if one of its selections overflowed its candidate
+    // lists the results are void: redo the call once with full-pass selection.
+    template <class F>
+    int with_select_retry(F&& body) {
+        int rc = body();
+        if (!safe_select && overflow_seen_) {
+            safe_select = true;
+            rc = body();
+            safe_select = false;
+        }
+        return rc;
+    }
 
     int check_flags(bool ifft_stage, bool final_stage, uint32_t* nan_ifft = nullptr, uint32_t* nan_final = nullptr) {
-        uint32_t f[8];
+        uint32_t f[12];                      // flags[8] + candidate counters[4]
         be.d2h(f, d_flags(), sizeof f, stream);
+        if (f[11] && !safe_select) { overflow_seen_ = true; return SMHIP_OK; }   // with_select_retry() redoes the call
         if (nan_ifft) *nan_ifft = f[0];
         if (nan_final) *nan_final = f[2];
         if (ifft_stage && f[1]) return fail(SMHIP_ERR_INF_IFFT, "Inf in ifft output");
@@ -728,6 +766,9 @@ class Pipeline {
     };
 
     int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
+        return with_select_retry([&] { return merge_layer_once(d, out_bf16, delta_out, rep); });
+    }
+    int merge_layer_once(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
         if (d.k < 1 || d.k > SMHIP_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
         const int R = d.rows, C = d.cols;
         if (R < 1 || C < 1) return fail(SMHIP_ERR_ARG, "bad shape");
@@ -735,7 +776,7 @@ class Pipeline {
         const Geo g = geo(R, C);
         int rc;
         if (!small_.p && (rc = reserve(1, 1))) return rc;
-        be.memset(d_flags(), 0, 32, stream);
+        clear_flags();
         smhip_layer_report local;
         smhip_layer_report& rp = rep ? *rep : local;
         memset(&rp, 0, sizeof rp);
@@ -948,7 +989,7 @@ class Pipeline {
         const Geo g = geo(R, C);
         int rc = reserve(R, C);
         if (rc) return rc;
-        be.memset(d_flags(), 0, 32, stream);
+        be.memset(d_flags(), 0, 32, stream);         // not the selection counters: blend_full calls this mid-way
         PackParams pk;
         pk.full = (const cf2*)spectrum; pk.R = R; pk.C = C; pk.Cb = g.Cb; pk.re = plane(g, P_RER); pk.im = plane(g, P_IMA);
         pk.chunks = 8; pk.sym = 1;
@@ -962,6 +1003,17 @@ class Pipeline {
     // weight 1 and the planes simply keep the row-major order of the input).
     int blend_full(const float* f0, const float* f1, int R, int C, int mode, double t, double t_sum, double cutoff_pct,
                    double cull_pct, int agreement, int do_imag, float* out_spec, smhip_blend_info* info) {
+        clear_flags();
+        int rc = blend_full_once(f0, f1, R, C, mode, t, t_sum, cutoff_pct, cull_pct, agreement, do_imag, out_spec, info);
+        if (rc == SMHIP_OK && !safe_select && select_overflowed()) {
+            safe_select = true;
+            rc = blend_full_once(f0, f1, R, C, mode, t, t_sum, cutoff_pct, cull_pct, agreement, do_imag, out_spec, info);
+            safe_select = false;
+        }
+        return rc;
+    }
+    int blend_full_once(const float* f0, const float* f1, int R, int C, int mode, double t, double t_sum, double cutoff_pct,
+                        double cull_pct, int agreement, int do_imag, float* out_spec, smhip_blend_info* info) {
         const Geo g = geo(R, C, true);
         int rc = reserve(R, C, true);
         if (rc) return rc;
@@ -1003,8 +1055,8 @@ class Pipeline {
         run_combine(rr, none, 1.f, 0.f, total, (float*)saveR_.p, nullptr, false);
         if ((rc = fft_transform(im0, R, C, (float*)tmpA_.p))) return rc;
         if ((rc = fft_transform(im1, R, C, (float*)tmpB_.p))) return rc;
-        if ((rc = blend_full((const float*)tmpA_.p, (const float*)tmpB_.p, R, C, mode, t, 1.0, 0, 0, agreement, 0,
-                             (float*)tmpC_.p, nullptr))) return rc;
+        if ((rc = blend_full_once((const float*)tmpA_.p, (const float*)tmpB_.p, R, C, mode, t, 1.0, 0, 0, agreement, 0,
+                                  (float*)tmpC_.p, nullptr))) return rc;
         if ((rc = ifft_transform((const float*)tmpC_.p, R, C, (float*)saveI_.p))) return rc;
         jp.re = (const float*)saveR_.p; jp.im = (const float*)saveI_.p;
         be.template launch<KJoin>(sgrid, 256, slds, jp, stream);
@@ -1016,6 +1068,7 @@ class Pipeline {
     std::map<int, HostPlan> plans_;
     Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
     uint32_t cap_keys_ = 0, cap_pairs_ = 0;
+    bool overflow_seen_ = false;
     std::vector<Buffer> inter_;
     std::vector<double> host_part_;
 };

@@ -81,10 +81,16 @@ def test_candidate_list_overflow_falls_back(engine, golden):
     kw = dict(b=case["b"], t_sum=case["t_sum"], cutoff_pct=case["cutoff"], cull_pct=case["cull"])
     ref, _, _, rep0 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
     engine.ctx.debug_option("cand_cap", 7)
+    engine.ctx.profile(True)
+    engine.ctx.profile_reset()
     try:
         out, _, _, rep1 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
+        launches = engine.ctx.profile_table()
     finally:
         engine.ctx.debug_option("cand_cap", 0)
+        engine.ctx.profile(False)
+    # the call was redone with the plain histogram passes (level 2 and 3 of both thresholds)
+    assert launches["select_hist"][0] == 4 and launches["f1_rows_fwd"][0] == 2
     assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())   # sums associate differently: ulps
     assert rep1.cutoff_threshold == rep0.cutoff_threshold and rep1.cull_threshold == rep0.cull_threshold
     assert rep1.n_slerp == rep0.n_slerp and rep1.s01 == pytest.approx(rep0.s01, rel=1e-9)
