@@ -40,6 +40,12 @@ SM_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 SM_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 SM_HD float bf16_to_f(uint32_t h) { return u2f(h << 16); }
 SM_HD float f16_to_f(uint32_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint16_t h16 = (uint16_t)h;                 // v_cvt_f32_f16
+    _Float16 hv;
+    memcpy(&hv, &h16, 2);
+    return (float)hv;
+#endif
     const uint32_t s = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
     if (e == 0) {
         if (m == 0) return u2f(s);
@@ -81,6 +87,20 @@ SM_HD void load_elem8(const void* p, int dtype, size_t i, float* out) {
                 out[2 * c] = f16_to_f(w[c] & 0xffffu);
                 out[2 * c + 1] = f16_to_f(w[c] >> 16);
             }
+        }
+    }
+}
+// 8 packed 16-bit values (bf16 or f16) -> float
+SM_HD void decode16x8(const u32x4& v, int dtype, float* out) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (dtype == DT_BF16) {
+            out[2 * c] = u2f(w[c] << 16);
+            out[2 * c + 1] = u2f(w[c] & 0xffff0000u);
+        } else {
+            out[2 * c] = f16_to_f(w[c] & 0xffffu);
+            out[2 * c + 1] = f16_to_f(w[c] >> 16);
         }
     }
 }
@@ -188,7 +208,59 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         const int row = bid * p.nb + g;
         const bool valid = row < p.R;
         double sa = 0.0, sb = 0.0;
-        if (vec) {
+        if (vec && p.a.dtype != DT_F32 && p.b.dtype != DT_F32) {
+            // 16-bit inputs (the merge itself): all 16-byte loads of the row are issued back
+            // to back - no load sits inside a divergent branch, out-of-range ones are
+            // clamped to element 0 and masked afterwards - and only then decoded
+            constexpr int NQ = EMAX / 8;
+            u32x4 ra[NQ], rab[NQ], rb[NQ], rbb[NQ];
+            bool ok[NQ];
+            size_t off[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int n0 = 8 * (t + q * T);
+                ok[q] = valid && n0 < C;
+                off[q] = ok[q] ? ((size_t)row * C + n0) / 8 : 0;
+            }
+            // an absent operand reads a's values instead (always there) and is masked out below
+            const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
+            const u32x4* pa = (const u32x4*)p.a.x;
+            const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
+            const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
+            const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) ra[q] = pa[off[q]];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rab[q] = pab[off[q]];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rb[q] = pb[off[q]];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rbb[q] = pbb[off[q]];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float va[8], vb[8], ba[8], bb[8];
+                decode16x8(ra[q], p.a.dtype, va);
+                decode16x8(rab[q], p.a.dtype, ba);
+                decode16x8(rb[q], p.b.dtype, vb);
+                decode16x8(rbb[q], p.b.dtype, bb);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (!has_ab) ba[c] = 0.f;
+                    if (!has_b) vb[c] = 0.f;
+                    if (!has_bb) bb[c] = 0.f;
+                }
+                const float ma = ok[q] ? p.a.prescale : 0.f, mb = ok[q] ? p.b.prescale : 0.f;
+                float pa = 0.f, pb = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xa = ok[q] ? (va[c] - ba[c]) * ma : 0.f;      // never NaN * 0 from a clamped load
+                    const float xb = ok[q] ? (vb[c] - bb[c]) * mb : 0.f;
+                    s.xr[q * 8 + c] = xa; s.xi[q * 8 + c] = xb;
+                    pa += xa * xa; pb += xb * xb;
+                }
+                sa += pa; sb += pb;
+            }
+        } else if (vec) {
 #pragma unroll
             for (int q = 0; q < EMAX / 8; ++q) {
                 const int n0 = 8 * (t + q * T);
@@ -680,22 +752,39 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         const int g = tid / T, t = tid % T;
         const int r0 = 2 * (bid * p.nb + g), r1 = r0 + 1;
         const bool v0 = r0 < p.R, v1 = r1 < p.R;
+        // loads are issued in two batches, none inside a divergent branch (out-of-range
+        // ones are clamped to a valid address and masked), so each batch is in flight together
+        const cf2* G0 = p.G + (size_t)(v0 ? r0 : 0) * p.pitchG;
+        const cf2* G1 = p.G + (size_t)(v1 ? r1 : 0) * p.pitchG;
+        constexpr int NU = EMAX / 2 + 1, HU = (NU + 1) / 2;
+        static_for<0, 2>([&](auto half_c) {
+            constexpr int u0 = decltype(half_c)::value * HU;
+            constexpr int u1 = (u0 + HU < NU) ? u0 + HU : NU;
+            cf2 a0[HU], a1[HU];
 #pragma unroll
-        for (int u = 0; u < EMAX / 2 + 1; ++u) {
-            const int k = t + u * T;
-            if (k < p.Cb) {
-                cf2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f};
-                if (v0) g0 = p.G[(size_t)r0 * p.pitchG + k];
-                if (v1) g1 = p.G[(size_t)r1 * p.pitchG + k];
-                if (k == 0 || 2 * k == C) { g0.y = 0.f; g1.y = 0.f; }   // c2r: DC / Nyquist are real
-                // Y[k] = G0[k] + i G1[k];  Y[C-k] = conj(G0[k]) + i conj(G1[k])
-                const float ykr = g0.x - g1.y, yki = g0.y + g1.x;
-                const float ymr = g0.x + g1.y, ymi = g1.x - g0.y;
-                // swap trick on input: feed (im, re)
-                s.xr[2 * u] = yki; s.xi[2 * u] = ykr;
-                s.xr[2 * u + 1] = ymi; s.xi[2 * u + 1] = ymr;
+            for (int u = u0; u < u1; ++u) {
+                const int k = t + u * T;
+                const int kc = k < p.Cb ? k : 0;
+                a0[u - u0] = G0[kc];
+                a1[u - u0] = G1[kc];
             }
-        }
+#pragma unroll
+            for (int u = u0; u < u1; ++u) {
+                const int k = t + u * T;
+                if (k < p.Cb) {
+                    cf2 g0 = a0[u - u0], g1 = a1[u - u0];
+                    if (!v0) { g0.x = 0.f; g0.y = 0.f; }
+                    if (!v1) { g1.x = 0.f; g1.y = 0.f; }
+                    if (k == 0 || 2 * k == C) { g0.y = 0.f; g1.y = 0.f; }   // c2r: DC / Nyquist are real
+                    // Y[k] = G0[k] + i G1[k];  Y[C-k] = conj(G0[k]) + i conj(G1[k])
+                    const float ykr = g0.x - g1.y, yki = g0.y + g1.x;
+                    const float ymr = g0.x + g1.y, ymi = g1.x - g0.y;
+                    // swap trick on input: feed (im, re)
+                    s.xr[2 * u] = yki; s.xi[2 * u] = ykr;
+                    s.xr[2 * u + 1] = ymi; s.xi[2 * u + 1] = ymr;
+                }
+            }
+        });
     });
 
     wg_fft<P>(ex, st, pl, lds,
@@ -747,6 +836,17 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
             if (row >= p.R) return;
             const float* x = comp_of<1 - h>(s);
             if (vec) {
+                // the add-back loads of the row (16-bit base: the merge itself) go out together
+                constexpr int NQ = EMAX / 8;
+                const bool base16 = p.base && p.base_dtype != DT_F32;
+                u32x4 braw[NQ];
+                if (base16) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int n0 = 8 * (t + q * T);
+                        braw[q] = ((const u32x4*)p.base)[n0 < C ? ((size_t)row * C + n0) / 8 : 0];
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < EMAX / 8; ++q) {
                     const int n0 = 8 * (t + q * T);
@@ -754,7 +854,8 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                         const size_t off = (size_t)row * C + n0;
                         float o[8];
                         float bv[8];
-                        if (p.base) load_elem8(p.base, p.base_dtype, off, bv);
+                        if (base16) decode16x8(braw[q], p.base_dtype, bv);
+                        else if (p.base) load_elem8(p.base, p.base_dtype, off, bv);
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
                             float v = x[q * 8 + c] * p.inv_n;
@@ -968,13 +1069,9 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     ex.each(st, [&](int tid, EmptyState& s) {
         double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
-        for (int c = 0; c < p.chunks; ++c) {
-            const size_t qi = start + (size_t)c * nt + tid;
-            if (qi >= nquad) break;
-            const size_t i0 = 4 * qi;
-            float a[4], b[4];
-            const int n = load_quad(p.X, i0, total, p.vec4, a);
-            if (p.Y) load_quad(p.Y, i0, total, p.vec4, b);
+        const bool hasY = p.Y != nullptr;
+        // up to 4 consecutive plane elements from i0 on
+        auto quad = [&](size_t i0, const float* a, const float* b, int n) {
             float q00 = 0.f, q01 = 0.f, q11 = 0.f, qc = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -986,7 +1083,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                         const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
                         if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = ka | ((w - 1u) << 31);
                     }
-                    if (p.Y) {
+                    if (hasY) {
                         const uint32_t kb = f2u(b[e]) & 0x7fffffffu;
                         const uint32_t binb = kb >> 20;
                         if (binb == prefix) {
@@ -1007,6 +1104,43 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 }
             }
             s00 += q00; s01 += q01; s11 += q11; cnt += qc;
+        };
+        if (p.vec4) {
+            // 16-byte loads, U steps in flight together: the address is clamped instead of
+            // branched around so that the loads issue back to back
+            constexpr int U = 4;
+            const cf4* X4 = (const cf4*)p.X;
+            const cf4* Y4 = (const cf4*)p.Y;
+            for (int c0 = 0; c0 < p.chunks; c0 += U) {
+                cf4 av[U], bv[U];
+                size_t qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    qv[u] = start + (size_t)(c0 + u) * nt + tid;
+                    av[u] = X4[qv[u] < nquad ? qv[u] : nquad - 1];
+                }
+                if (hasY) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) bv[u] = Y4[qv[u] < nquad ? qv[u] : nquad - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u < p.chunks && qv[u] < nquad) {
+                        const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+                        const float b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+                        quad(4 * qv[u], a, b, 4);
+                    }
+                }
+            }
+        } else {
+            for (int c = 0; c < p.chunks; ++c) {
+                const size_t qi = start + (size_t)c * nt + tid;
+                if (qi >= nquad) break;
+                float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
+                const int n = load_quad(p.X, 4 * qi, total, 0, a);
+                if (hasY) load_quad(p.Y, 4 * qi, total, 0, b);
+                quad(4 * qi, a, b, n);
+            }
         }
         s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
     });
