@@ -184,9 +184,10 @@ struct F1Params {
     SigDesc a, b;
     int R, C, Cb;
     int pitch4;            // T1 row pitch in float4
+    int ilv;               // rows interleaved in T1 (1, 2 or 4): element (r, k) at ((r/ilv)*pitch4 + k)*ilv + r%ilv
     int nb;                // rows (transforms) per work-group
     int vec;               // 1: C % 8 == 0 and 16-byte aligned inputs
-    cf4* t1;
+    cf4* t1;               // the column pass reads ilv*16 contiguous bytes per (row group, bin)
     double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
 };
 
@@ -198,7 +199,10 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
     const FftPlanDev& pl = p.plan;
     const int T = plan_T<P>(pl), C = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
-    const int bid = ex.bid();
+    // the work-groups of an interleaved row group fill the same 128-byte lines: they sit
+    // on one XCD, adjacent in dispatch order, so the partial-line writes merge in that L2
+    const int bid = (p.ilv > p.nb) ? xcd_remap(ex.bid(), p.ilv / p.nb) : ex.bid();
+    const int pbid = ex.bid();
     // static plans are launched only when the 16-byte vector path applies (host checks),
     // so the element-wise path is not even compiled into them
     const bool vec = P::is_static ? true : (p.vec != 0);
@@ -298,8 +302,8 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         s.red[0] = sa; s.red[1] = sb;
     });
     ex.template block_sum<2>(st, [&](const double* tot) {
-        p.partials[2 * (size_t)bid] = tot[0];
-        p.partials[2 * (size_t)bid + 1] = tot[1];
+        p.partials[2 * (size_t)pbid] = tot[0];
+        p.partials[2 * (size_t)pbid + 1] = tot[1];
     });
 
     wg_fft<P>(ex, st, pl, lds,
@@ -349,14 +353,14 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         const int g = tid / T, t = tid % T;
         const int row = bid * p.nb + g;
         if (row >= p.R) return;
-        cf4* dst = p.t1 + (size_t)row * p.pitch4;
+        cf4* dst = p.t1 + (size_t)(row / p.ilv) * p.pitch4 * p.ilv + (row % p.ilv);
 #pragma unroll
         for (int u = 0; u < EMAX / 2 + 1; ++u) {
             const int k = t + u * T;
             if (k < p.Cb) {
                 cf4 v;
                 v.x = s.xr[2 * u]; v.y = s.xi[2 * u]; v.z = s.xi[2 * u + 1]; v.w = s.xr[2 * u + 1];
-                dst[k] = v;
+                dst[(size_t)k * p.ilv] = v;
             }
         }
     });
@@ -369,6 +373,7 @@ struct F2Params {
     FftPlanDev plan;       // N = R
     const cf4* t1;
     int pitch4;
+    int ilv;               // see F1Params
     int R, C, Cb;
     int nsig;              // 2: A and B in one work-group; 1: one signal per work-group
     int swap;              // 1: slot B plays role "a" (the larger-norm input)
@@ -404,20 +409,29 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         if (ng == 2) {
             const int b = tid % BINS, lane = tid / BINS;
             const int k2 = kbase + b;
+            // slot q holds row f2_row(lane, q): ILV consecutive rows of a thread are one
+            // contiguous ILV*16-byte piece of T1
+            auto load_rows = [&](auto ilv_c) {
+                constexpr int ILV = decltype(ilv_c)::value;
 #pragma unroll
-            for (int q = 0; q < EMAX / 2; ++q) {
-                const int n = lane + q * 2 * T;
-                cf4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < R && k2 < p.Cb) v = p.t1[(size_t)n * p.pitch4 + k2];
-                s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
-            }
+                for (int q = 0; q < EMAX / 2; ++q) {
+                    const int m = lane + (q / ILV) * 2 * T;               // row group
+                    const int n = m * ILV + q % ILV;
+                    cf4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (n < R && k2 < p.Cb) v = p.t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
+                    s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
+                }
+            };
+            if (p.ilv == 4) load_rows(std::integral_constant<int, 4>{});
+            else if (p.ilv == 2) load_rows(std::integral_constant<int, 2>{});
+            else load_rows(std::integral_constant<int, 1>{});
         } else {
 #pragma unroll
             for (int q = 0; q < EMAX; ++q) {
                 const int n = tid + q * T;
                 float re = 0.f, im = 0.f;
                 if (n < R) {
-                    const cf2* src = (const cf2*)(p.t1 + (size_t)n * p.pitch4 + kbase) + slot0;
+                    const cf2* src = (const cf2*)(p.t1 + ((size_t)(n / p.ilv) * p.pitch4 + kbase) * p.ilv + n % p.ilv) + slot0;
                     re = src->x; im = src->y;
                 }
                 s.xr[q] = re; s.xi[q] = im;
@@ -433,11 +447,17 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
             if (ng == 2) {
                 const int b = tid % BINS, lane = tid / BINS;
                 float* la = lds + (2 * b) * LF;
+                auto scatter_rows = [&](auto ilv_c) {
+                    constexpr int ILV = decltype(ilv_c)::value;
 #pragma unroll
-                for (int q = 0; q < EMAX / 2; ++q) {
-                    const int n = lane + q * 2 * T;
-                    if (n < R) { la[lpad(n)] = x[2 * q]; la[LF + lpad(n)] = x[2 * q + 1]; }
-                }
+                    for (int q = 0; q < EMAX / 2; ++q) {
+                        const int n = (lane + (q / ILV) * 2 * T) * ILV + q % ILV;
+                        if (n < R) { la[lpad(n)] = x[2 * q]; la[LF + lpad(n)] = x[2 * q + 1]; }
+                    }
+                };
+                if (p.ilv == 4) scatter_rows(std::integral_constant<int, 4>{});
+                else if (p.ilv == 2) scatter_rows(std::integral_constant<int, 2>{});
+                else scatter_rows(std::integral_constant<int, 1>{});
             } else {
 #pragma unroll
                 for (int q = 0; q < EMAX; ++q) {

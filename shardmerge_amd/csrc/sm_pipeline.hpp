@@ -239,7 +239,7 @@ class Pipeline {
     }
 
     struct Geo {
-        int R, C, Cb, pitch4, pitchG;
+        int R, C, Cb, pitch4, pitchG, ilv;
         size_t plane_floats;      // one plane, padded
         bool full;                // planes hold the full spectrum (weights 1)
         int Cw;                   // C passed to bin_weight (-1 in full mode)
@@ -250,15 +250,27 @@ class Pipeline {
         g.Cb = full ? C : C / 2 + 1;
         g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
         g.pitchG = 2 * g.pitch4;
+        g.ilv = t1_interleave(R);
         g.plane_floats = round_up((size_t)g.Cb * R, 64);
         g.Cw = full ? -1 : C;
         return g;
     }
+    // rows interleaved in the forward intermediate T1: the column pass then reads ilv*16
+    // contiguous bytes per thread instead of 16 (its strided 16-byte reads ran at a third
+    // of the HBM rate), the row pass pays with ilv work-groups sharing each line it writes
+    // (measured on MI355X: pairs pay off from 8192 rows on, groups of 4 never)
+#ifndef SM_T1_ILV
+#define SM_T1_ILV 2
+#endif
+#ifndef SM_T1_ILV_MIN_ROWS
+#define SM_T1_ILV_MIN_ROWS 8192
+#endif
+    static int t1_interleave(int R) { return R >= SM_T1_ILV_MIN_ROWS ? SM_T1_ILV : 1; }
     static constexpr int MAXGRID_PART = 1 << 20;
     int reserve(int R, int C, bool full = false) {
         const Geo g = geo(R, C, full);
         int rc;
-        if ((rc = ensure(t1_, (size_t)R * g.pitch4 * sizeof(cf4)))) return rc;
+        if ((rc = ensure(t1_, round_up((size_t)R, 4) * g.pitch4 * sizeof(cf4)))) return rc;
         if ((rc = ensure(planes_, 4 * g.plane_floats * sizeof(float)))) return rc;
         {   // candidate lists of the selection passes: ~1 % of the data is expected
             const size_t ck = std::max<size_t>(1 << 16, g.plane_floats / 4), cp = std::max<size_t>(1 << 15, g.plane_floats / 16);
@@ -358,12 +370,13 @@ class Pipeline {
         F1Params p;
         int rc = get_plan(g.C, p.plan);
         if (rc) return rc;
-        p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4;
+        p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = g.ilv;
         p.nb = std::max(1, 256 / p.plan.T);
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
-        const int grid = (g.R + p.nb - 1) / p.nb;
+        const int xg = p.ilv > p.nb ? p.ilv / p.nb : 1;
+        const int grid = (int)round_up((size_t)(g.R + p.nb - 1) / p.nb, 8 * xg);
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
         launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
@@ -384,14 +397,14 @@ class Pipeline {
         int rc = get_plan(g.R, p.plan);
         if (rc) return rc;
         if (g.R == 1) {
-            p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = 1; p.C = g.C; p.Cb = g.C / 2 + 1; p.nsig = 2;
+            p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = 1; p.R = 1; p.C = g.C; p.Cb = g.C / 2 + 1; p.nsig = 2;
             p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
             p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
             p.hist = hist ? d_hist() : nullptr;
             be.template launch<KF2R1>(std::max(1, std::min(64, (p.Cb + 255) / 256)), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, p, stream);
             return SMHIP_OK;
         }
-        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
+        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = g.ilv; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
         p.nsig = (2 * p.plan.T <= SM_COLS_MAX_THREADS) ? 2 : 1;
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
