@@ -51,6 +51,9 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
 #define SM_COLS_MAX_THREADS 1024
 #endif
 // experiment knobs for the 8192-point plan (override with -D on the hipcc line)
+#ifndef SM_R14336
+#define SM_R14336 16, 16, 8, 7
+#endif
 #ifndef SM_T8192
 #define SM_T8192 256
 #define SM_W8192 4
@@ -63,7 +66,7 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
     X(SPlan<4096, 128, false, 4, 16, 16, 16>)  \
     X(SPlan<8192, SM_T8192, false, SM_W8192, SM_R8192>)  \
     X(SPlan<16384, 512, false, 4, 32, 32, 16>)\
-    X(SPlan<14336, 512, false, 4, 16, 16, 8, 7>) \
+    X(SPlan<14336, 512, false, 4, SM_R14336>) \
     X(SPlan<28672, 1024, false, 4, 16, 16, 16, 7>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -

@@ -32,6 +32,7 @@ def load(d, counter):
 
 
 NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI1x2": "i1_cols_inv", "KI2": "i2_rows_inv",
+         "KF2R1": "f2_cols_fwd", "KI1R1": "i1_cols_inv",
          "KSelect2": "select_lvl2", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
 
 
