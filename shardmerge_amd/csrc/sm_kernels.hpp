@@ -36,6 +36,7 @@ struct SigDesc {
     float prescale;
 };
 
+SM_HD uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 SM_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 SM_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 SM_HD float bf16_to_f(uint32_t h) { return u2f(h << 16); }
@@ -60,6 +61,20 @@ SM_HD uint16_t f_to_bf16(float v) {
     uint32_t u = f2u(v);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+// two floats -> packed bf16 pair (lo = a), round-to-nearest-even; neither is NaN
+SM_HD uint32_t pack_bf16x2(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);      // v_cvt_pk_bf16_f32
+    uint32_t u;
+    memcpy(&u, &h, 4);
+    return u;
+#else
+    return (uint32_t)f_to_bf16(a) | ((uint32_t)f_to_bf16(b) << 16);
+#endif
 }
 SM_HD bool is_nan(float v) { return v != v; }
 SM_HD bool is_inf(float v) { return (f2u(v) & 0x7fffffffu) == 0x7f800000u; }
@@ -240,30 +255,39 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             for (int q = 0; q < NQ; ++q) rb[q] = pb[off[q]];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) rbb[q] = pbb[off[q]];
+            // MASKED: some loads of this thread were clamped (ragged row tail, padded grid)
+            auto decode = [&](auto masked_c) {
+                constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float va[8], vb[8], ba[8], bb[8];
-                decode16x8(ra[q], p.a.dtype, va);
-                decode16x8(rab[q], p.a.dtype, ba);
-                decode16x8(rb[q], p.b.dtype, vb);
-                decode16x8(rbb[q], p.b.dtype, bb);
+                for (int q = 0; q < NQ; ++q) {
+                    float va[8], vb[8], ba[8], bb[8];
+                    decode16x8(ra[q], p.a.dtype, va);
+                    decode16x8(rab[q], p.a.dtype, ba);
+                    decode16x8(rb[q], p.b.dtype, vb);
+                    decode16x8(rbb[q], p.b.dtype, bb);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (!has_ab) ba[c] = 0.f;
-                    if (!has_b) vb[c] = 0.f;
-                    if (!has_bb) bb[c] = 0.f;
+                    for (int c = 0; c < 8; ++c) {
+                        if (!has_ab) ba[c] = 0.f;
+                        if (!has_b) vb[c] = 0.f;
+                        if (!has_bb) bb[c] = 0.f;
+                    }
+                    float pa = 0.f, pb = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float xa = (va[c] - ba[c]) * p.a.prescale;
+                        float xb = (vb[c] - bb[c]) * p.b.prescale;
+                        if (MASKED && !ok[q]) { xa = 0.f; xb = 0.f; }      // never NaN * 0 from a clamped load
+                        s.xr[q * 8 + c] = xa; s.xi[q * 8 + c] = xb;
+                        pa += xa * xa; pb += xb * xb;
+                    }
+                    sa += pa; sb += pb;
                 }
-                const float ma = ok[q] ? p.a.prescale : 0.f, mb = ok[q] ? p.b.prescale : 0.f;
-                float pa = 0.f, pb = 0.f;
+            };
+            bool all_ok = true;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float xa = ok[q] ? (va[c] - ba[c]) * ma : 0.f;      // never NaN * 0 from a clamped load
-                    const float xb = ok[q] ? (vb[c] - bb[c]) * mb : 0.f;
-                    s.xr[q * 8 + c] = xa; s.xi[q * 8 + c] = xb;
-                    pa += xa * xa; pb += xb * xb;
-                }
-                sa += pa; sb += pb;
-            }
+            for (int q = 0; q < NQ; ++q) all_ok = all_ok && ok[q];
+            if (all_ok) decode(std::false_type{});
+            else decode(std::true_type{});
         } else if (vec) {
 #pragma unroll
             for (int q = 0; q < EMAX / 8; ++q) {
@@ -876,27 +900,41 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                         float bv[8];
                         if (base16) decode16x8(braw[q], p.base_dtype, bv);
                         else if (p.base) load_elem8(p.base, p.base_dtype, off, bv);
+                        // fast path: no NaN/Inf anywhere in the group (an all-ones exponent is
+                        // looked for with an and + max per value); otherwise the exact policy
+                        uint32_t e1 = 0, e2 = 0;
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            float v = x[q * 8 + c] * p.inv_n;
-                            if (p.ifft_policy) {
-                                if (is_nan(v)) { v = 0.f; nan1++; }
-                                if (is_inf(v)) inf1 = 1;
+                            const float v1 = x[q * 8 + c] * p.inv_n;
+                            e1 = umax(e1, f2u(v1) & 0x7f800000u);
+                            float v2 = v1 * p.post;
+                            if (p.base) v2 += bv[c];
+                            e2 = umax(e2, f2u(v2) & 0x7f800000u);
+                            o[c] = v2;
+                        }
+                        if ((p.ifft_policy && e1 == 0x7f800000u) || e2 == 0x7f800000u) {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                float v = x[q * 8 + c] * p.inv_n;
+                                if (p.ifft_policy) {
+                                    if (is_nan(v)) { v = 0.f; nan1++; }
+                                    if (is_inf(v)) inf1 = 1;
+                                }
+                                v *= p.post;
+                                if (p.base) {
+                                    v += bv[c];
+                                    if (is_nan(v)) { v = 0.f; nan2++; }
+                                    if (is_inf(v)) inf2 = 1;
+                                }
+                                o[c] = v;
                             }
-                            v *= p.post;
-                            if (p.base) {
-                                v += bv[c];
-                                if (is_nan(v)) { v = 0.f; nan2++; }
-                                if (is_inf(v)) inf2 = 1;
-                            }
-                            o[c] = v;
                         }
                         if (p.out_mode == OUT_BF16) {
                             u32x4 w;
-                            w.x = (uint32_t)f_to_bf16(o[0]) | ((uint32_t)f_to_bf16(o[1]) << 16);
-                            w.y = (uint32_t)f_to_bf16(o[2]) | ((uint32_t)f_to_bf16(o[3]) << 16);
-                            w.z = (uint32_t)f_to_bf16(o[4]) | ((uint32_t)f_to_bf16(o[5]) << 16);
-                            w.w = (uint32_t)f_to_bf16(o[6]) | ((uint32_t)f_to_bf16(o[7]) << 16);
+                            w.x = pack_bf16x2(o[0], o[1]);
+                            w.y = pack_bf16x2(o[2], o[3]);
+                            w.z = pack_bf16x2(o[4], o[5]);
+                            w.w = pack_bf16x2(o[6], o[7]);
                             ((u32x4*)p.out)[off / 8] = w;
                         } else {
                             cf4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
