@@ -102,12 +102,22 @@ def run_step(engines, layers, k):
     import threading
     counts = [0] * len(engines)
     errors = []
+    # shared work queue in model order: neighbouring tensors differ in shape, so the streams run
+    # different kernels side by side (sorting by size made all of them run the same kernel: slower)
+    order = list(range(len(layers)))
+    cursor = [0]
+    lock = threading.Lock()
 
     def work(w):
         eng, stream = engines[w]
         try:
             with torch.cuda.stream(stream):
-                for i in range(w, len(layers), len(engines)):
+                while True:
+                    with lock:
+                        if cursor[0] >= len(order):
+                            break
+                        i = order[cursor[0]]
+                        cursor[0] += 1
                     base, fts = layers[i]
                     out, rep = eng.merge_layer(fts, [base] * k, ALPHAS[:k], base)
                     counts[w] += out.numel()
@@ -147,7 +157,7 @@ def main():
     ap.add_argument("--workload", default="llama3-8b")
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--k", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4, help="tensors merged concurrently (one engine/stream/workspace each)")
+    ap.add_argument("--streams", type=int, default=8, help="tensors merged concurrently (one engine/stream/workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
