@@ -39,6 +39,25 @@ constexpr int MAX_PASSES = 8;
 
 struct cf2 { float x, y; };
 
+// Two floats side by side.  The butterflies below are templates over the value type:
+// with V = vf2 one instruction stream does two isomorphic butterflies of a thread at once
+// (lane = butterfly), which the gfx950 packed-f32 ALU ops (v_pk_add/mul/fma_f32) execute
+// at the price of one - with no lane shuffles, because the two lanes never mix.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float vf2 __attribute__((ext_vector_type(2)));
+SM_HD vf2 mk2(float a, float b) { vf2 v; v.x = a; v.y = b; return v; }
+#else
+struct vf2 { float x, y; };
+SM_HD vf2 mk2(float a, float b) { vf2 v; v.x = a; v.y = b; return v; }
+SM_HD vf2 operator+(vf2 a, vf2 b) { return mk2(a.x + b.x, a.y + b.y); }
+SM_HD vf2 operator-(vf2 a, vf2 b) { return mk2(a.x - b.x, a.y - b.y); }
+SM_HD vf2 operator*(vf2 a, vf2 b) { return mk2(a.x * b.x, a.y * b.y); }
+SM_HD vf2 operator*(vf2 a, float b) { return mk2(a.x * b, a.y * b); }
+SM_HD vf2 operator*(float a, vf2 b) { return mk2(a * b.x, a * b.y); }
+SM_HD vf2 operator-(vf2 a) { return mk2(-a.x, -a.y); }
+SM_HD vf2& operator+=(vf2& a, vf2 b) { a = a + b; return a; }
+#endif
+
 // plan of one N-point transform, passed to kernels by value
 struct FftPlanDev {
     int N;                 // transform length
@@ -58,25 +77,29 @@ SM_HD void static_for(F&& f) {
     }
 }
 
+template <class V> SM_HD V vzero();
+template <> SM_HD float vzero<float>() { return 0.f; }
+template <> SM_HD vf2 vzero<vf2>() { return mk2(0.f, 0.f); }
+
 // LDS padding: one spare word per 32 breaks the power-of-two strides of the
 // radix scatters (stride-16 words would otherwise be a 16-way bank conflict).
 SM_HD int lpad(int o) { return o + (o >> 5); }
 
 // ---- multiply by W32^E (compile-time exponent) --------------------------------
-template <int E>
-SM_HD void mul_w32(float& r, float& i) {
+template <int E, class V>
+SM_HD void mul_w32(V& r, V& i) {
     constexpr int e = ((E % 32) + 32) % 32;
     if constexpr (e == 0) {
     } else if constexpr (e == 8) {          // * (-i)
-        float t = r; r = i; i = -t;
+        V t = r; r = i; i = -t;
     } else if constexpr (e == 16) {
         r = -r; i = -i;
     } else if constexpr (e == 24) {         // * (+i)
-        float t = r; r = -i; i = t;
+        V t = r; r = -i; i = t;
     } else {
         constexpr float c = W32_RE[e];
         constexpr float s = W32_IM[e];
-        float t = r * c - i * s;
+        V t = r * c - i * s;
         i = r * s + i * c;
         r = t;
     }
@@ -85,23 +108,23 @@ SM_HD void mul_w32(float& r, float& i) {
 // ---- small in-register DFTs (forward, natural order in and out) ----------------
 template <int R> struct Dft;
 
-template <> struct Dft<1> { static SM_HD void run(float*, float*) {} };
+template <> struct Dft<1> { template <class V> static SM_HD void run(V*, V*) {} };
 
 template <> struct Dft<2> {
-    static SM_HD void run(float* re, float* im) {
-        float ar = re[0], ai = im[0];
+    template <class V> static SM_HD void run(V* re, V* im) {
+        V ar = re[0], ai = im[0];
         re[0] = ar + re[1]; im[0] = ai + im[1];
         re[1] = ar - re[1]; im[1] = ai - im[1];
     }
 };
 
 template <> struct Dft<4> {
-    static SM_HD void run(float* re, float* im) {
-        float t0r = re[0] + re[2], t0i = im[0] + im[2];
-        float t1r = re[0] - re[2], t1i = im[0] - im[2];
-        float t2r = re[1] + re[3], t2i = im[1] + im[3];
-        float dr = re[1] - re[3], di = im[1] - im[3];
-        float t3r = di, t3i = -dr;                       // (x1-x3) * (-i)
+    template <class V> static SM_HD void run(V* re, V* im) {
+        V t0r = re[0] + re[2], t0i = im[0] + im[2];
+        V t1r = re[0] - re[2], t1i = im[0] - im[2];
+        V t2r = re[1] + re[3], t2i = im[1] + im[3];
+        V dr = re[1] - re[3], di = im[1] - im[3];
+        V t3r = di, t3i = -dr;                           // (x1-x3) * (-i)
         re[0] = t0r + t2r; im[0] = t0i + t2i;
         re[2] = t0r - t2r; im[2] = t0i - t2i;
         re[1] = t1r + t3r; im[1] = t1i + t3i;
@@ -113,12 +136,12 @@ template <> struct Dft<4> {
 // B-point DFTs, outputs written to natural positions k1 + A*k2.
 template <int A, int B>
 struct DftComposite {
-    static SM_HD void run(float* re, float* im) {
+    template <class V> static SM_HD void run(V* re, V* im) {
         constexpr int N = A * B;
-        float yr[N], yi[N];
+        V yr[N], yi[N];
         static_for<0, B>([&](auto b_) {
             constexpr int b = decltype(b_)::value;
-            float tr[A], ti[A];
+            V tr[A], ti[A];
             static_for<0, A>([&](auto a_) {
                 constexpr int a = decltype(a_)::value;
                 tr[a] = re[B * a + b]; ti[a] = im[B * a + b];
@@ -126,14 +149,14 @@ struct DftComposite {
             Dft<A>::run(tr, ti);
             static_for<0, A>([&](auto k_) {
                 constexpr int k1 = decltype(k_)::value;
-                float r = tr[k1], i = ti[k1];
+                V r = tr[k1], i = ti[k1];
                 mul_w32<(b * k1) * (32 / N)>(r, i);
                 yr[k1 * B + b] = r; yi[k1 * B + b] = i;
             });
         });
         static_for<0, A>([&](auto k_) {
             constexpr int k1 = decltype(k_)::value;
-            float tr[B], ti[B];
+            V tr[B], ti[B];
             static_for<0, B>([&](auto b_) {
                 constexpr int b = decltype(b_)::value;
                 tr[b] = yr[k1 * B + b]; ti[b] = yi[k1 * B + b];
@@ -147,9 +170,29 @@ struct DftComposite {
     }
 };
 
-template <> struct Dft<8> { static SM_HD void run(float* re, float* im) { DftComposite<2, 4>::run(re, im); } };
-template <> struct Dft<16> { static SM_HD void run(float* re, float* im) { DftComposite<4, 4>::run(re, im); } };
-template <> struct Dft<32> { static SM_HD void run(float* re, float* im) { DftComposite<4, 8>::run(re, im); } };
+template <> struct Dft<8> { template <class V> static SM_HD void run(V* re, V* im) { DftComposite<2, 4>::run(re, im); } };
+template <> struct Dft<16> { template <class V> static SM_HD void run(V* re, V* im) { DftComposite<4, 4>::run(re, im); } };
+// 32 = 2 x 16 decimation in time with the even- and the odd-indexed 16-point transforms
+// side by side in the two lanes; only the last radix-2 stage (and the odd half's W32^k)
+// is done on single floats.  (A thread holds ONE radix-32 butterfly, so there is no
+// second butterfly to pair with as for the smaller radices.)
+template <> struct Dft<32> {
+    static SM_HD void run(float* re, float* im) {
+        vf2 er[16], ei[16];
+        static_for<0, 16>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            er[i] = mk2(re[2 * i], re[2 * i + 1]); ei[i] = mk2(im[2 * i], im[2 * i + 1]);
+        });
+        Dft<16>::run(er, ei);
+        static_for<0, 16>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            float orr = er[k].y, oi = ei[k].y;
+            mul_w32<k>(orr, oi);
+            re[k] = er[k].x + orr; im[k] = ei[k].x + oi;
+            re[k + 16] = er[k].x - orr; im[k + 16] = ei[k].x - oi;
+        });
+    }
+};
 
 template <int P> struct OddTab;
 template <> struct OddTab<3> { SM_HD static constexpr float c(int m) { return ODD3_COS[m]; } SM_HD static constexpr float s(int m) { return ODD3_SIN[m]; } };
@@ -162,27 +205,27 @@ template <> struct OddTab<13> { SM_HD static constexpr float c(int m) { return O
 // P_k = x0 + sum_j cos(2 pi j k / P)(x_j + x_{P-j}),  Q_k = sum_j sin(2 pi j k / P)(x_j - x_{P-j})
 template <int P>
 struct DftOdd {
-    static SM_HD void run(float* re, float* im) {
+    template <class V> static SM_HD void run(V* re, V* im) {
         constexpr int H = (P - 1) / 2;
-        float sr[H + 1], si[H + 1], dr[H + 1], di[H + 1];
-        float x0r = re[0], x0i = im[0];
-        float accr = x0r, acci = x0i;
+        V sr[H + 1], si[H + 1], dr[H + 1], di[H + 1];
+        V x0r = re[0], x0i = im[0];
+        V accr = x0r, acci = x0i;
         static_for<1, H + 1>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             sr[j] = re[j] + re[P - j]; si[j] = im[j] + im[P - j];
             dr[j] = re[j] - re[P - j]; di[j] = im[j] - im[P - j];
-            accr += sr[j]; acci += si[j];
+            accr = accr + sr[j]; acci = acci + si[j];
         });
         re[0] = accr; im[0] = acci;
         static_for<1, H + 1>([&](auto k_) {
             constexpr int k = decltype(k_)::value;
-            float pr = x0r, pi = x0i, qr = 0.f, qi = 0.f;
+            V pr = x0r, pi = x0i, qr = vzero<V>(), qi = vzero<V>();
             static_for<1, H + 1>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 constexpr float c = OddTab<P>::c((j * k) % P);
                 constexpr float s = OddTab<P>::s((j * k) % P);
-                pr += c * sr[j]; pi += c * si[j];
-                qr += s * dr[j]; qi += s * di[j];
+                pr = pr + sr[j] * c; pi = pi + si[j] * c;
+                qr = qr + dr[j] * s; qi = qi + di[j] * s;
             });
             re[k] = pr + qi; im[k] = pi - qr;
             re[P - k] = pr - qi; im[P - k] = pi + qr;
@@ -206,11 +249,11 @@ SM_HD void mul_w28(float& r, float& i) {
     }
 }
 
-template <> struct Dft<3> { static SM_HD void run(float* re, float* im) { DftOdd<3>::run(re, im); } };
-template <> struct Dft<5> { static SM_HD void run(float* re, float* im) { DftOdd<5>::run(re, im); } };
-template <> struct Dft<7> { static SM_HD void run(float* re, float* im) { DftOdd<7>::run(re, im); } };
-template <> struct Dft<11> { static SM_HD void run(float* re, float* im) { DftOdd<11>::run(re, im); } };
-template <> struct Dft<13> { static SM_HD void run(float* re, float* im) { DftOdd<13>::run(re, im); } };
+template <> struct Dft<3> { template <class V> static SM_HD void run(V* re, V* im) { DftOdd<3>::run(re, im); } };
+template <> struct Dft<5> { template <class V> static SM_HD void run(V* re, V* im) { DftOdd<5>::run(re, im); } };
+template <> struct Dft<7> { template <class V> static SM_HD void run(V* re, V* im) { DftOdd<7>::run(re, im); } };
+template <> struct Dft<11> { template <class V> static SM_HD void run(V* re, V* im) { DftOdd<11>::run(re, im); } };
+template <> struct Dft<13> { template <class V> static SM_HD void run(V* re, V* im) { DftOdd<13>::run(re, im); } };
 
 // 28 = 4 x 7 (the 7 * 2^k lengths of Llama / Mixtral MLP tensors: 14336 = 32*16*28)
 template <> struct Dft<28> {
@@ -327,30 +370,42 @@ SM_HD void pass_scatter(const float* x, float* lds, int N, int Ns, int T, int t)
     }
 }
 
-SM_HD void cmul(float& ar, float& ai, float br, float bi) {
-    const float r = ar * br - ai * bi;
+template <class V>
+SM_HD void cmul(V& ar, V& ai, V br, V bi) {
+    const V r = ar * br - ai * bi;
     ai = ar * bi + ai * br;
     ar = r;
 }
+
+// twiddle table entry for one butterfly (float) or for the two of a packed pair (vf2)
+SM_HD void tw_load(const cf2* tw, int idx, int, float& wr, float& wi) { const cf2 w = tw[idx]; wr = w.x; wi = w.y; }
+SM_HD void tw_load(const cf2* tw, int idx0, int idx1, vf2& wr, vf2& wi) {
+    const cf2 w0 = tw[idx0], w1 = tw[idx1];
+    wr = mk2(w0.x, w1.x); wi = mk2(w0.y, w1.y);
+}
+template <class V> SM_HD V vone();
+template <> SM_HD float vone<float>() { return 1.f; }
+template <> SM_HD vf2 vone<vf2>() { return mk2(1.f, 1.f); }
 
 // multiply x[i] by w^i, i = 1..R-1, w = W_{Ns*R}^k.  Only the powers w^(2^b) are
 // loaded from the table (exact to half an ulp); the others are products of at
 // most three of them, so a radix-16 butterfly costs 4 table loads instead of 15
 // and keeps 16 instead of 30 registers of twiddles alive.  (A base-4 digit
 // variant with 12 registers measured slower on MI355X: more multiplies and, in
-// this code, more spills.)
-template <int R>
-SM_HD void apply_twiddles(float* xr, float* xi, const cf2* tw, int kidx) {
+// this code, more spills.)  kidx1 is the second lane's index when V = vf2.
+template <int R, class V>
+SM_HD void apply_twiddles(V* xr, V* xi, const cf2* tw, int kidx0, int kidx1) {
     constexpr int LOGR = R <= 2 ? 1 : R <= 4 ? 2 : R <= 8 ? 3 : R <= 16 ? 4 : 5;
     constexpr int HALF = 1 << (LOGR - 1);              // top power of two used
-    float pr[LOGR], pi[LOGR];
+    V pr[LOGR], pi[LOGR];
 #pragma unroll
     for (int b = 0; b < LOGR; ++b) {
-        if ((1 << b) < R) { const cf2 w = tw[kidx << b]; pr[b] = w.x; pi[b] = w.y; } else { pr[b] = 1.f; pi[b] = 0.f; }
+        if ((1 << b) < R) tw_load(tw, kidx0 << b, kidx1 << b, pr[b], pi[b]);
+        else { pr[b] = vone<V>(); pi[b] = vzero<V>(); }
     }
     // low powers w^1 .. w^(HALF-1)
-    float lr[HALF], li[HALF];
-    lr[0] = 1.f; li[0] = 0.f;
+    V lr[HALF], li[HALF];
+    lr[0] = vone<V>(); li[0] = vzero<V>();
     static_for<1, HALF>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int top = (i >= 16) ? 4 : (i >= 8) ? 3 : (i >= 4) ? 2 : (i >= 2) ? 1 : 0;
@@ -366,31 +421,54 @@ SM_HD void apply_twiddles(float* xr, float* xi, const cf2* tw, int kidx) {
     });
 }
 
-template <int R>
+template <int R, bool PACK = true>
 SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const cf2* tw) {
     constexpr int MB = EMAX / R;
     const int nb = N / R;
     const int tstep = N / (Ns * R);
+    if constexpr (PACK && MB >= 2 && MB % 2 == 0 && R <= 16) {
+        // the thread's butterflies j = t + m*T go through the same arithmetic: two at a time,
+        // side by side in the lanes of a vf2 (the second of a pair may lie beyond the last
+        // butterfly: its lane computes on stale values that nobody stores)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        const int j = t + m * T;
-        if (j < nb) {
-            if (Ns > 1) {
-                const int k = j % Ns;
-                if constexpr (R <= 32 && R != 28) {        // every radix a plan uses with twiddles
-                    apply_twiddles<R>(xr + m * R, xi + m * R, tw, k * tstep);
-                } else {
+        for (int m = 0; m < MB; m += 2) {
+            const int j0 = t + m * T, j1 = j0 + T;
+            if (j0 < nb) {
+                vf2 re[R], im[R];
 #pragma unroll
-                    for (int i = 1; i < R; ++i) {
-                        const cf2 w = tw[i * k * tstep];
-                        cmul(xr[m * R + i], xi[m * R + i], w.x, w.y);
-                    }
+                for (int i = 0; i < R; ++i) {
+                    re[i] = mk2(xr[m * R + i], xr[(m + 1) * R + i]);
+                    im[i] = mk2(xi[m * R + i], xi[(m + 1) * R + i]);
+                }
+                if (Ns > 1) apply_twiddles<R>(re, im, tw, (j0 % Ns) * tstep, (j1 % Ns) * tstep);
+                Dft<R>::run(re, im);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    xr[m * R + i] = re[i].x; xr[(m + 1) * R + i] = re[i].y;
+                    xi[m * R + i] = im[i].x; xi[(m + 1) * R + i] = im[i].y;
                 }
             }
-            Dft<R>::run(xr + m * R, xi + m * R);
-#ifdef SM_USE_SCHED_FENCE
-            if (MB > 1) SM_SCHED_FENCE();
-#endif
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+                if (Ns > 1) {
+                    const int k = j % Ns;
+                    if constexpr (R <= 32 && R != 28) {        // every radix a plan uses with twiddles
+                        apply_twiddles<R>(xr + m * R, xi + m * R, tw, k * tstep, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 1; i < R; ++i) {
+                            const cf2 w = tw[i * k * tstep];
+                            cmul(xr[m * R + i], xi[m * R + i], w.x, w.y);
+                        }
+                    }
+                }
+                if constexpr (R == 32 && !PACK) DftComposite<4, 8>::run(xr + m * R, xi + m * R);
+                else Dft<R>::run(xr + m * R, xi + m * R);
+            }
         }
     }
 }
@@ -431,7 +509,9 @@ template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::i
 //   fin_gather(tid, state, comp_c): read from LDS (natural order X[k]) what the
 //        storer needs of component comp.
 // State must expose float xr[EREG], xi[EREG].
-template <class P, class Ex, class StT, class NatScatter, class FinGather>
+// PACK = false keeps every butterfly on single floats (the inverse column pass spills
+// registers with the paired form and loses more than the shorter instruction stream wins)
+template <class P, bool PACK = true, class Ex, class StT, class NatScatter, class FinGather>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
@@ -450,7 +530,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
             constexpr int r = P::radix(p);
             constexpr int Ns = P::ns(p);
             constexpr bool last = (p + 1 == P::npass);
-            ex.each(st, [&](int tid, S& s) { pass_compute<r>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw); });
+            ex.each(st, [&](int tid, S& s) { pass_compute<r, PACK>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw); });
             static_for<0, 2>([&](auto comp_c) {
                 constexpr int comp = decltype(comp_c)::value;
                 ex.each(st, [&](int tid, S& s) {
@@ -483,7 +563,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
         for (int p = 0; p < pl.npass; ++p) {
             const int r = pl.radix[p];
             ex.each(st, [&](int tid, S& s) {
-                SM_RADIX_SWITCH(r, pass_compute<RX>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw));
+                SM_RADIX_SWITCH(r, (pass_compute<RX, PACK>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw)));
             });
             const bool last = (p + 1 == pl.npass);
             static_for<0, 2>([&](auto comp_c) {

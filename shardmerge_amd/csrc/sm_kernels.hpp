@@ -672,7 +672,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         }
     });
 
-    wg_fft<P>(ex, st, pl, lds,
+    wg_fft<P, false>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
