@@ -971,7 +971,15 @@ struct EmptyState { double red[8]; };
 
 SM_HD int sgn(float v) { return (v > 0.f) - (v < 0.f); }
 // torch.sign(NaN) = NaN and NaN == NaN is False: NaNs never "agree"
-SM_HD bool same_sign(float a, float b) { return !is_nan(a) && !is_nan(b) && sgn(a) == sgn(b); }
+// (on the bit patterns: |x| > inf is a NaN, |x| == 0 is a zero of either sign)
+SM_HD bool same_sign(float a, float b) {
+    const uint32_t ua = f2u(a), ub = f2u(b);
+    const uint32_t ka = ua & 0x7fffffffu, kb = ub & 0x7fffffffu;
+    const bool not_nan = ka <= 0x7f800000u && kb <= 0x7f800000u;
+    const bool za = ka == 0u, zb = kb == 0u;
+    const bool both_nonzero_same = !za && !zb && ((ua ^ ub) >> 31) == 0u;
+    return not_nan && ((za && zb) || both_nonzero_same);
+}
 
 
 // selection state (device memory): exact k-th smallest key by radix levels
@@ -1129,12 +1137,14 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
         const bool hasY = p.Y != nullptr;
         // up to 4 consecutive plane elements from i0 on
-        auto quad = [&](size_t i0, const float* a, const float* b, int n) {
+        // uniform_w: the 4 elements lie in one column (R % 4 == 0), one weight serves all
+        auto quad = [&](size_t i0, const float* a, const float* b, int n, bool uniform_w) {
             float q00 = 0.f, q01 = 0.f, q11 = 0.f, qc = 0.f;
+            const uint32_t w0 = weight_at(wr, i0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e < n) {
-                    const uint32_t w = weight_at(wr, i0 + e);
+                    const uint32_t w = uniform_w ? w0 : weight_at(wr, i0 + e);
                     const uint32_t ka = f2u(a[e]) & 0x7fffffffu;
                     if ((ka >> 20) == prefix) {
                         ex.lds_atomic_add(&lh[(ka >> 10) & 1023u], w);
@@ -1186,7 +1196,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                     if (c0 + u < p.chunks && qv[u] < nquad) {
                         const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
                         const float b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
-                        quad(4 * qv[u], a, b, 4);
+                        quad(4 * qv[u], a, b, 4, !wr.full);
                     }
                 }
             }
@@ -1197,7 +1207,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
                 const int n = load_quad(p.X, 4 * qi, total, 0, a);
                 if (hasY) load_quad(p.Y, 4 * qi, total, 0, b);
-                quad(4 * qi, a, b, n);
+                quad(4 * qi, a, b, n, false);
             }
         }
         s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
