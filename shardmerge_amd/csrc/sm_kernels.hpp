@@ -289,26 +289,67 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             if (all_ok) decode(std::false_type{});
             else decode(std::true_type{});
         } else if (vec) {
+            // any other dtype mix (later tournament rounds: an fp32 intermediate against a raw
+            // bf16 delta): one signal at a time, its loads issued together, decoded afterwards
+            constexpr int NQ = EMAX / 8;
+            bool ok[NQ];
+            size_t off[NQ];
 #pragma unroll
-            for (int q = 0; q < EMAX / 8; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int n0 = 8 * (t + q * T);
-                float va[8], vb[8];
-                if (valid && n0 < C) {
-                    const size_t off = (size_t)row * C + n0;
-                    load_sig8(p.a, off, va);
-                    load_sig8(p.b, off, vb);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) { va[c] = 0.f; vb[c] = 0.f; }
-                }
-                float pa = 0.f, pb = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    s.xr[q * 8 + c] = va[c]; s.xi[q * 8 + c] = vb[c];
-                    pa += va[c] * va[c]; pb += vb[c] * vb[c];
-                }
-                sa += pa; sb += pb;
+                ok[q] = valid && n0 < C;
+                off[q] = ok[q] ? (size_t)row * C + n0 : 0;
             }
+            auto load_signal = [&](const SigDesc& sg, float* dst, double& ss) {
+                if (!sg.x) {
+#pragma unroll
+                    for (int i = 0; i < 8 * NQ; ++i) dst[i] = 0.f;
+                    return;
+                }
+                const bool has_base = sg.base != nullptr;
+                float v[NQ][8], bv[NQ][8];
+                if (sg.dtype == DT_F32) {
+                    const cf4* px = (const cf4*)sg.x;
+                    const cf4* pb = has_base ? (const cf4*)sg.base : px;
+                    cf4 r[NQ][2], rb[NQ][2];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { r[q][0] = px[off[q] / 4]; r[q][1] = px[off[q] / 4 + 1]; }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { rb[q][0] = pb[off[q] / 4]; rb[q][1] = pb[off[q] / 4 + 1]; }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const cf4 x0 = r[q][0], x1 = r[q][1], b0 = rb[q][0], b1 = rb[q][1];
+                        const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) { v[q][c] = xs[c]; bv[q][c] = bs[c]; }
+                    }
+                } else {
+                    const u32x4* px = (const u32x4*)sg.x;
+                    const u32x4* pb = has_base ? (const u32x4*)sg.base : px;
+                    u32x4 r[NQ], rb[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) r[q] = px[off[q] / 8];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) rb[q] = pb[off[q] / 8];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) { decode16x8(r[q], sg.dtype, v[q]); decode16x8(rb[q], sg.dtype, bv[q]); }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float ps = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float x = (v[q][c] - (has_base ? bv[q][c] : 0.f)) * sg.prescale;
+                        if (!ok[q]) x = 0.f;
+                        dst[q * 8 + c] = x;
+                        ps += x * x;
+                    }
+                    ss += ps;
+                }
+            };
+            load_signal(p.a, s.xr, sa);
+            load_signal(p.b, s.xi, sb);
         } else {
 #pragma unroll
             for (int q = 0; q < EMAX; ++q) {
@@ -764,6 +805,7 @@ struct I2Params {
     const void* base; int base_dtype;   // add-back tensor or null
     void* out; int out_mode;
     uint32_t* flags;       // [0] NaNs zeroed after ifft, [1] Inf after ifft, [2] NaNs zeroed after add-back, [3] Inf after add-back
+    double* norm_partials; // [grid][2] or null: sum of squares of what this work-group stored (next round's ||merged||)
 };
 
 SM_HD void i2_finish(const I2Params& p, float v, size_t off, uint32_t& nan1, uint32_t& inf1, uint32_t& nan2, uint32_t& inf2, float& outv) {
@@ -873,6 +915,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         const int g = tid / T, t = tid % T;
         const int r0 = 2 * (bid * p.nb + g);
         uint32_t nan1 = 0, inf1 = 0, nan2 = 0, inf2 = 0;
+        double ss = 0.0;
         // after the swap trick the true (re, im) = (xi, xr): row r0 = re, row r0+1 = im
         static_for<0, 2>([&](auto h_c) {
             constexpr int h = decltype(h_c)::value;
@@ -929,6 +972,12 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                                 o[c] = v;
                             }
                         }
+                        if (p.norm_partials) {
+                            float ps = 0.f;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) ps += o[c] * o[c];
+                            ss += ps;
+                        }
                         if (p.out_mode == OUT_BF16) {
                             u32x4 w;
                             w.x = pack_bf16x2(o[0], o[1]);
@@ -951,6 +1000,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
                         const size_t off = (size_t)row * C + n;
                         float v;
                         i2_finish(p, x[q], off, nan1, inf1, nan2, inf2, v);
+                        ss += (double)v * v;
                         if (p.out_mode == OUT_BF16) ((uint16_t*)p.out)[off] = f_to_bf16(v);
                         else ((float*)p.out)[off] = v;
                     }
@@ -961,7 +1011,15 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         if (inf1) ex.global_atomic_or_u32(&p.flags[1], 1u);
         if (nan2) ex.global_atomic_add_u32(&p.flags[2], nan2);
         if (inf2) ex.global_atomic_or_u32(&p.flags[3], 1u);
+        s.red[0] = ss; s.red[1] = 0.0;
     });
+    if (p.norm_partials) {
+        ex.sync();
+        ex.template block_sum<2>(st, [&](const double* tot) {
+            p.norm_partials[2 * (size_t)bid] = tot[0];
+            p.norm_partials[2 * (size_t)bid + 1] = 0.0;
+        });
+    }
 }
 
 // =====================================================================
@@ -1650,7 +1708,57 @@ SM_HD void k_combine(Ex& ex, const CombineParams& p) {
         double sa = 0, sb = 0;
         uint32_t nan2 = 0, inf2 = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
-        for (int q = 0; q < p.chunks; ++q) {
+        // 16-bit inputs, no finishing stage (the norms of the raw deltas, K >= 3): the loads of
+        // U octets go out together, clamped instead of branched around, and are decoded afterwards
+        const bool fast16 = p.vec8 && !p.out_final && p.a.x && p.a.dtype != DT_F32 && (!p.b.x || p.b.dtype != DT_F32);
+        if (fast16) {
+            constexpr int U = 4;
+            const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
+            const u32x4* pa = (const u32x4*)p.a.x;
+            const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
+            const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
+            const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
+            for (int q0 = 0; q0 < p.chunks; q0 += U) {
+                u32x4 ra[U], rab[U], rb[U], rbb[U];
+                size_t oc[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const size_t oi = start + (size_t)(q0 + u) * nt + tid;
+                    ok[u] = (q0 + u) < p.chunks && oi < noct;
+                    oc[u] = ok[u] ? oi : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) ra[u] = pa[oc[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) rab[u] = pab[oc[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) rb[u] = pb[oc[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) rbb[u] = pbb[oc[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    float va[8], ba[8], vb[8], bb[8], o[8];
+                    decode16x8(ra[u], p.a.dtype, va); decode16x8(rab[u], p.a.dtype, ba);
+                    decode16x8(rb[u], p.b.dtype, vb); decode16x8(rbb[u], p.b.dtype, bb);
+                    float pa2 = 0.f, pb2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xa = (va[e] - (has_ab ? ba[e] : 0.f)) * p.a.prescale;
+                        const float xb = has_b ? (vb[e] - (has_bb ? bb[e] : 0.f)) * p.b.prescale : 0.f;
+                        pa2 += xa * xa; pb2 += xb * xb;
+                        o[e] = p.ca * xa + (has_b ? p.cb * xb : 0.f);
+                    }
+                    sa += pa2; sb += pb2;
+                    if (p.out_f32) {
+                        cf4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
+                        ((cf4*)p.out_f32)[2 * oc[u]] = w0; ((cf4*)p.out_f32)[2 * oc[u] + 1] = w1;
+                    }
+                }
+            }
+        }
+        for (int q = 0; q < (fast16 ? 0 : p.chunks); ++q) {
             const size_t oi = start + (size_t)q * nt + tid;
             if (oi >= noct) break;
             const size_t i0 = 8 * oi;

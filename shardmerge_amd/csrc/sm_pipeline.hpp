@@ -511,7 +511,10 @@ class Pipeline {
         be.template launch<KSlerpConsts>(1, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
     }
 
-    int run_inverse(const Geo& g, const float* reR, const float* imA, const float* cull_thr, const PairOut& o) {
+    // norm_grid (optional): the row pass also leaves the sum of squares of what it stores in
+    // d_part(), *norm_grid work-groups of it (read_norms() finishes the reduction)
+    int run_inverse(const Geo& g, const float* reR, const float* imA, const float* cull_thr, const PairOut& o,
+                    int* norm_grid = nullptr) {
         I1Params a;
         int rc = get_plan(g.R, a.plan);
         if (rc) return rc;
@@ -540,6 +543,8 @@ class Pipeline {
         b.flags = d_flags();
         const int pairs = (g.R + 1) / 2;
         const int grid2 = (pairs + b.nb - 1) / b.nb;
+        b.norm_partials = (norm_grid && (size_t)grid2 * 2 <= PART_DOUBLES) ? d_part() : nullptr;
+        if (norm_grid) *norm_grid = b.norm_partials ? grid2 : -1;
         const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
         launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
         return SMHIP_OK;
@@ -555,7 +560,7 @@ class Pipeline {
         c.flags = d_flags();
         c.vec8 = (n % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base) &&
                  aligned16(out_f32) && aligned16(c.base) && aligned16(c.out_final);
-        c.chunks = 4;
+        c.chunks = pick_chunks((n + 7) / 8, 256, 4, 8);
         int grid = stream_grid((n + 7) / 8, 256, c.chunks);
         while ((size_t)grid * 2 > PART_DOUBLES) { c.chunks *= 2; grid = stream_grid((n + 7) / 8, 256, c.chunks); }
         c.partials = want_norms ? d_part() : nullptr;
@@ -896,6 +901,7 @@ class Pipeline {
                     po.out = inter; po.out_mode = OUT_F32; po.post = 1.f;
                 }
                 int branch;
+                int inv_grid = -1;      // >= 0: work-groups of the inverse row pass that left norm partials
                 smhip_blend_info info;
                 memset(&info, 0, sizeof info);
                 double out_norm = -1;
@@ -944,7 +950,8 @@ class Pipeline {
                         ps.post = (float)target_norm;                       // merged * target_norm (fast_fourier.py:243)
                         float* dtmp = nullptr;
                         if (last_round && delta_out) { ps = PairOut(); ps.out = delta_out; ps.post = (float)target_norm; dtmp = delta_out; }
-                        if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, ps))) return rc;
+                        if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, ps,
+                                              last_round ? nullptr : &inv_grid))) return rc;
                         if (dtmp) {
                             SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
                             run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
@@ -959,8 +966,8 @@ class Pipeline {
                 if (!last_round) {
                     // the next round needs ||merged|| (fast_fourier.py:209-210)
                     SigDesc ms{inter, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
-                    int grid;
-                    run_combine(ms, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
+                    int grid = inv_grid;             // the inverse row pass summed the squares it stored
+                    if (grid < 0) run_combine(ms, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
                     double nm, dummy;
                     read_norms(grid, nm, dummy);
                     out_norm = nm;
