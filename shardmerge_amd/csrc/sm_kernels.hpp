@@ -1190,6 +1190,13 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
         if (tid < 8) lctl[tid] = 0;
     });
     ex.sync();
+    // The stream is cut into rounds of ROUND steps; after each round the staged candidates go
+    // to the global lists, so a work-group's staging area only has to hold one round's worth
+    // (a 235 M-element tensor used to overflow it - and redo the whole layer in safe mode)
+    constexpr int ROUND = 16;
+    ex.each(st, [&](int, EmptyState& s) { s.red[0] = s.red[1] = s.red[2] = s.red[3] = 0.0; });
+    for (int r0 = 0; r0 < p.chunks; r0 += ROUND) {
+    const int r1 = (r0 + ROUND < p.chunks) ? r0 + ROUND : p.chunks;
     ex.each(st, [&](int tid, EmptyState& s) {
         double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
@@ -1237,7 +1244,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             constexpr int U = 4;
             const cf4* X4 = (const cf4*)p.X;
             const cf4* Y4 = (const cf4*)p.Y;
-            for (int c0 = 0; c0 < p.chunks; c0 += U) {
+            for (int c0 = r0; c0 < r1; c0 += U) {
                 cf4 av[U], bv[U];
                 size_t qv[U];
 #pragma unroll
@@ -1251,7 +1258,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (c0 + u < p.chunks && qv[u] < nquad) {
+                    if (c0 + u < r1 && qv[u] < nquad) {
                         const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
                         const float b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
                         quad(4 * qv[u], a, b, 4, !wr.full);
@@ -1259,7 +1266,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 }
             }
         } else {
-            for (int c = 0; c < p.chunks; ++c) {
+            for (int c = r0; c < r1; ++c) {
                 const size_t qi = start + (size_t)c * nt + tid;
                 if (qi >= nquad) break;
                 float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1268,9 +1275,13 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 quad(4 * qi, a, b, n, false);
             }
         }
-        s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
+        s.red[0] += s00; s.red[1] += s01; s.red[2] += s11; s.red[3] += cnt;
     });
     ex.sync();
+    // flush when the staging area is more than half full (the counts are the same for every
+    // thread after the barrier, so the branch is uniform), and at the end
+    const bool last_round = r1 >= p.chunks;
+    if (!last_round && lctl[0] <= (uint32_t)STAGE_KEYS / 2 && lctl[1] <= (uint32_t)STAGE_PAIRS / 2) continue;
     ex.each(st, [&](int tid, EmptyState&) {
         if (tid == 0) {
             uint32_t nk = lctl[0], np = lctl[1];
@@ -1286,13 +1297,19 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     });
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
+        const uint32_t nk = lctl[0], np = lctl[1], bk = lctl[2], bp = lctl[3];
+        for (uint32_t q = tid; q < nk; q += nt) if (bk + q < p.cand.cap_keys) p.cand.keys[bk + q] = lkeys[q];
+        for (uint32_t q = tid; q < np; q += nt) if (bp + q < p.cand.cap_pairs) p.cand.pairs[bp + q] = lpairs[q];
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) { if (tid < 4) lctl[tid] = 0; });
+    ex.sync();
+    }   // rounds
+    ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid; b < HIST_LO_BINS; b += nt) {
             const uint32_t v = lh[b];
             if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
         }
-        const uint32_t nk = lctl[0], np = lctl[1], bk = lctl[2], bp = lctl[3];
-        for (uint32_t q = tid; q < nk; q += nt) if (bk + q < p.cand.cap_keys) p.cand.keys[bk + q] = lkeys[q];
-        for (uint32_t q = tid; q < np; q += nt) if (bp + q < p.cand.cap_pairs) p.cand.pairs[bp + q] = lpairs[q];
     });
     if (p.fuse_reduce) {
         ex.sync();
