@@ -188,6 +188,33 @@ def test_full_size_scale_equivariance_and_determinism(engine, full_inputs):
     assert abs(rep1.merged_delta_norm / rep1.target_norm - 1) < 0.2
 
 
+@pytest.mark.parametrize("shape", [(8192, 8192), (28672, 4096)], ids=["8192sq", "70B_mlp_half"])
+def test_large_tensors_take_the_fast_selection_path(engine, shape):
+    """The candidate lists of the selection passes must not overflow on ordinary data at
+    BASELINE's sizes (an overflow redoes the whole layer with full histogram passes: correct,
+    but twice the time - it happened silently at the Llama-3-70B shapes)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g, device="cuda") * s).to(torch.bfloat16) for s in (0.002, 0.003)]
+    engine.ctx.profile(True)
+    engine.ctx.profile_reset()
+    try:
+        out, rep = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)
+        table = engine.ctx.profile_table()
+    finally:
+        engine.ctx.profile(False)
+    assert rep.branches == ["slerp"]
+    assert table["f1_rows_fwd"][0] == 1 and table["i2_rows_inv"][0] == 1        # one pass, no retry
+    assert "select_hist" not in table and "slerp_reduce" not in table          # no safe-mode kernels
+    # exact order statistics at full size, checked against torch on the device: the cull
+    # threshold is the 20 % quantile position of |Re R| over the full spectrum - here only its
+    # sanity (the parity tests check values at sizes the oracle can do)
+    info = rep.infos[0]
+    assert info.cull_threshold > info.cutoff_threshold > 0
+    del out, fts, base
+    torch.cuda.empty_cache()
+
+
 def test_cli_end_to_end_on_device(tmp_path, golden):
     """`python -m shard merge CONFIG` (device: cuda) on the tiny on-disk model of G8:
     files, index, README and tensors against the reference CLI's output."""
