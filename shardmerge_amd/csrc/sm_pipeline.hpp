@@ -50,6 +50,9 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
 #ifndef SM_COLS_MAX_THREADS
 #define SM_COLS_MAX_THREADS 1024
 #endif
+#ifndef SM_F2_MAX_THREADS
+#define SM_F2_MAX_THREADS 512
+#endif
 // experiment knobs for the 8192-point plan (override with -D on the hipcc line)
 #ifndef SM_R14336
 #define SM_R14336 16, 16, 8, 7
@@ -408,7 +411,10 @@ class Pipeline {
             return SMHIP_OK;
         }
         p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = g.ilv; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
-        p.nsig = (2 * p.plan.T <= SM_COLS_MAX_THREADS) ? 2 : 1;
+        // A and B of a bin in one work-group up to 512 threads; longer columns (T = 512: 14336,
+        // 16384 rows) run one signal per work-group: two independent 512-thread groups per CU
+        // overlap their phases, which beats the 16-byte reads of one lock-step 1024-thread group
+        p.nsig = (2 * p.plan.T <= SM_F2_MAX_THREADS) ? 2 : 1;
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
         p.hist = hist ? d_hist() : nullptr;
