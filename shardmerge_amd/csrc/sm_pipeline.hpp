@@ -30,10 +30,13 @@ template <class P, int GROUPS> constexpr int fft_max_threads() {
     if constexpr (P::is_static) return (GROUPS * P::T < 256) ? 256 : (GROUPS * P::T > 1024 ? 1024 : GROUPS * P::T);
     else return 1024;
 }
+#ifndef SM_W3_MAX_THREADS
+#define SM_W3_MAX_THREADS 256
+#endif
 #define SM_FFT_KERNEL_TAG(Tag, ParamsT, NAME, CALL, GROUPS, WAVES)                   \
     template <class P> struct Tag {                                                  \
         using Params = ParamsT;                                                      \
-        static constexpr int waves = (WAVES < 4 && P::is_static && fft_max_threads<P, GROUPS>() <= 512) ? WAVES : 4; \
+        static constexpr int waves = (WAVES < 4 && P::is_static && fft_max_threads<P, GROUPS>() <= SM_W3_MAX_THREADS) ? WAVES : 4; \
         static constexpr int max_threads = waves < 4 ? fft_max_threads<P, GROUPS>() : 1024; \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
