@@ -5,8 +5,9 @@
 from __future__ import annotations
 
 import logging
+import os
 from abc import ABC, abstractmethod
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -21,6 +22,8 @@ class MergeTensorsBase(ABC):
     def __init__(self, config: MergeConfig, index_manager: Optional[LocalModelIndex] = None):
         self.config = config
         self.index_manager = index_manager or LocalModelIndex(config.storage_path, config.cache_path)
+        self._loader = None             # PrefetchLoader while merge() runs (loader.py)
+        self._layer_pos = {}
 
     @abstractmethod
     def get_readme(self) -> str:
@@ -30,7 +33,16 @@ class MergeTensorsBase(ABC):
     async def _merge_layer(self, shard_layer: ShardLayer, device: str) -> torch.Tensor:
         raise NotImplementedError
 
+    def _layer_requests(self, shard_layer: ShardLayer) -> List[Tuple[str, str]]:
+        """(model uri, tensor name) pairs `_merge_layer` will fetch for this layer, in any order;
+        operators that list them get their inputs prefetched (loader.py), others load on demand."""
+        return []
+
     async def _fetch(self, model_uri: str, layer_name: str, device: str) -> torch.Tensor:
+        if self._loader is not None:
+            t = self._loader.take(model_uri, layer_name)
+            if t is not None:
+                return t
         return await self.index_manager.get_tensor(model_uri, layer_name, device=device).get()
 
     async def get_base_output_tensor(self, shard_layer: ShardLayer, device: str) -> torch.Tensor:
@@ -66,6 +78,10 @@ class MergeTensorsBase(ABC):
                     f"Model {m.model} architecture mismatch with base model {cfg.output_base_model}\n"
                     f"Missing keys: {base_keys - keys}\nExtra keys: {keys - base_keys}")
 
+    def _loader_device(self, device: str) -> str:
+        """device the prefetched tensors must land on (operators with an engine override this)"""
+        return device
+
     def get_writer(self, layer_order: List[str]) -> ModelWriter:
         return ModelWriter(base_index=self.index_doc, output_path=self.config.output_path,
                            layer_order=layer_order, output_astype=self.config.output_astype)
@@ -74,8 +90,21 @@ class MergeTensorsBase(ABC):
         await self.initialize()
         layer_order = self.index_manager.get_layer_order(self.config.output_base_model)
         writer = self.get_writer(layer_order)
-        for group in writer.shard_layers():
-            await self._process_layers(writer, [sl for sl in group if not sl.written], device)
+        groups = [[sl for sl in group if not sl.written] for group in writer.shard_layers()]
+        todo = [sl for group in groups for sl in group]
+        schedule = [self._layer_requests(sl) for sl in todo]
+        if os.environ.get("SHARDMERGE_PREFETCH", "1") != "0" and any(schedule):
+            from ..loader import PrefetchLoader
+            self._layer_pos = {sl.layer_name: i for i, sl in enumerate(todo)}
+            self._loader = PrefetchLoader(self.index_manager, self._loader_device(device))
+            self._loader.start(schedule)
+        try:
+            for group in groups:
+                await self._process_layers(writer, group, device)
+        finally:
+            if self._loader is not None:
+                self._loader.close()
+                self._loader = None
         writer.finalize()
         readme = self.get_readme() or "No README defined"
         with open(self.config.output_path / "README.md", "w") as fh:
@@ -86,6 +115,8 @@ class MergeTensorsBase(ABC):
         shard_layer = None
         try:
             for shard_layer in shard_layers:
+                if self._loader is not None:
+                    self._loader.begin_layer(self._layer_pos[shard_layer.layer_name])
                 out = await self._merge_layer(shard_layer, device)
                 writer.add_tensor(shard_layer.layer_name, out)
                 del out

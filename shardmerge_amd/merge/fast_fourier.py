@@ -53,6 +53,22 @@ class FourierMerge(MergeTensorsBase):
         models = "\n".join(f"- {m.model} (vs {m.base})" for m in self.config.finetune_merge)
         return f"# SLERP-FFT Merged Model\nBase: {self.config.output_base_model}\nModels merged:\n{models}\n"
 
+    def _loader_device(self, device: str) -> str:
+        return str(self.engine(device).device)
+
+    def _layer_requests(self, shard_layer: ShardLayer):
+        """what _merge_layer below fetches (kept next to it on purpose)"""
+        number, name = shard_layer.layer_number, shard_layer.layer_name
+        if number in (INPUT_LAYER, OUTPUT_LAYER):
+            flag = "is_input" if number == INPUT_LAYER else "is_output"
+            src = next((m for m in self.config.finetune_merge if getattr(m, flag)), None)
+            return [(src.model if src is not None else self.config.output_base_model, name)]
+        models = [m for m in self.config.finetune_merge if m.use_layer_index(number)]
+        if not models:
+            return []
+        uris = [m.model for m in models] + [m.base for m in models] + [self.config.output_base_model]
+        return [(u, name) for u in dict.fromkeys(uris)]
+
     async def _passthrough(self, flag: str, shard_layer: ShardLayer, device: str) -> torch.Tensor:
         src = next((m for m in self.config.finetune_merge if getattr(m, flag)), None)
         uri = src.model if src is not None else self.config.output_base_model

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""End-to-end `python -m shard merge` on an on-disk synthetic model:
+writes base + K finetunes with Llama-3-8B block shapes under a RAM-backed directory, then
+runs the CLI's merge with the prefetching loader on and off and prints one JSON line per run
+(wall time includes reading the safetensors shards, H2D, the merge, D2H and writing the output).
+
+    python tools/cli_bench.py [--blocks 4] [--k 2] [--root /dev/shm/smcli] [--device cuda]
+"""
+import argparse
+import asyncio
+import json
+import os
+import shutil
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+import yaml
+from safetensors.torch import save_file
+
+BLOCK = [("self_attn.q_proj.weight", 4096, 4096), ("self_attn.k_proj.weight", 1024, 4096),
+         ("self_attn.v_proj.weight", 1024, 4096), ("self_attn.o_proj.weight", 4096, 4096),
+         ("mlp.gate_proj.weight", 14336, 4096), ("mlp.up_proj.weight", 14336, 4096),
+         ("mlp.down_proj.weight", 4096, 14336), ("input_layernorm.weight", 1, 4096),
+         ("post_attention_layernorm.weight", 1, 4096)]
+SIGMA = (0.002, 0.003, 0.0025, 0.004)
+
+
+def write_models(root: Path, blocks: int, k: int, gen_device: str):
+    storage = root / "storage"
+    uris = ["org/base"] + [f"org/ft{i}" for i in range(1, k + 1)]
+    g = torch.Generator(device=gen_device).manual_seed(1000)
+    total = 0
+    for b in range(-1, blocks + 1):               # -1: embed shard, blocks: norm + lm_head shard
+        if b == -1:
+            items = [("model.embed_tokens.weight", 2048, 4096)]
+            shard = "model-embed.safetensors"
+        elif b == blocks:
+            items = [("model.norm.weight", 1, 4096), ("lm_head.weight", 2048, 4096)]
+            shard = "model-head.safetensors"
+        else:
+            items = [(f"model.layers.{b}.{n}", r, c) for n, r, c in BLOCK]
+            shard = f"model-{b:05d}.safetensors"
+        base = {}
+        for name, r, c in items:
+            shape = (c,) if r == 1 else (r, c)
+            base[name] = (torch.randn(shape, generator=g, device=gen_device) * 0.02).to(torch.bfloat16)
+        for which, uri in enumerate(uris):
+            d = storage / uri
+            d.mkdir(parents=True, exist_ok=True)
+            if which == 0:
+                tens = {n: t.cpu() for n, t in base.items()}
+            else:
+                tens = {n: (t.float() + torch.randn(t.shape, generator=g, device=gen_device) * SIGMA[which - 1]).to(torch.bfloat16).cpu()
+                        for n, t in base.items()}
+            save_file(tens, str(d / shard), metadata={"format": "pt"})
+            idx_path = d / "model.safetensors.index.json"
+            doc = json.load(open(idx_path)) if idx_path.exists() else {"metadata": {"total_size": 0}, "weight_map": {}}
+            doc["weight_map"].update({n: shard for n in tens})
+            json.dump(doc, open(idx_path, "w"))
+            if which == 0:
+                total += sum(t.numel() for t in tens.values())
+    cfg = {"output_base_model": "org/base",
+           "finetune_merge": [{"model": f"org/ft{i}", "base": "org/base", "alpha": (0.3, 0.5, 0.2, 0.4)[i - 1], "is_input": i == 1}
+                              for i in range(1, k + 1)],
+           "output_dir": str(root / "merged"), "output_dtype": "bfloat16", "device": "cuda",
+           "cache_dir": str(root / "cache"), "storage_dir": str(storage)}
+    p = root / "merge.yaml"
+    yaml.safe_dump(cfg, open(p, "w"))
+    return p, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--root", default="/dev/shm/smcli")
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    root = Path(args.root)
+    if root.exists():
+        shutil.rmtree(root)
+    root.mkdir(parents=True)
+    t0 = time.time()
+    cfg_path, n_params = write_models(root, args.blocks, args.k, args.device if torch.cuda.is_available() else "cpu")
+    print(f"# wrote {args.k + 1} models, {n_params / 1e6:.0f} M params each, in {time.time() - t0:.1f} s under {root}", file=sys.stderr)
+
+    from shardmerge_amd.__main__ import run_merge
+    from shardmerge_amd.config import MergeConfig
+    for prefetch in ("0", "1", "0", "1"):
+        os.environ["SHARDMERGE_PREFETCH"] = prefetch
+        out_dir = root / "merged"
+        if out_dir.exists():
+            shutil.rmtree(out_dir)
+        config = MergeConfig.from_yaml(cfg_path)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t0 = time.time()
+        asyncio.run(run_merge(config, args.device, clean_cache=False))
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(json.dumps({"cli_merge": "end to end", "prefetch": prefetch == "1", "blocks": args.blocks, "k": args.k,
+                          "params": n_params, "seconds": round(dt, 3), "merged_GBps": round(2.0 * n_params / dt / 1e9, 3),
+                          "input_GB": round(2.0 * n_params * (args.k + 1) / 1e9, 2)}))
+    if not args.keep:
+        shutil.rmtree(root)
+
+
+if __name__ == "__main__":
+    main()
