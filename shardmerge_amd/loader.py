@@ -14,7 +14,9 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import threading
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -52,14 +54,12 @@ class ShardFile:
         rec = self.entries[name]
         off0, off1 = rec["data_offsets"]
         view = memoryview(dst.numpy()).cast("B")
-        with self.lock:
-            self.fh.seek(self.data_start + off0)
-            got = 0
-            while got < off1 - off0:
-                k = self.fh.readinto(view[got:])
-                if not k:
-                    raise IOError(f"short read of {name} in {self.path}")
-                got += k
+        fd, pos, got = self.fh.fileno(), self.data_start + off0, 0
+        while got < off1 - off0:                       # positional reads: safe from several threads
+            k = os.preadv(fd, [view[got:got + (1 << 30)]], pos + got)
+            if not k:
+                raise IOError(f"short read of {name} in {self.path}")
+            got += k
 
     def close(self):
         self.fh.close()
@@ -83,6 +83,7 @@ class PrefetchLoader:
         self.stop = False
         self.cursor = 0                # layer the consumer is at
         self.bytes_read = 0
+        self.pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="shardmerge-read")
 
     # ---- producer ---------------------------------------------------------------------
     def start(self, schedule: Sequence[Sequence[Request]]):
@@ -99,7 +100,9 @@ class PrefetchLoader:
         return f
 
     def _load(self, uri: str, name: str):
-        f = self._file(uri, name)
+        if self.on_gpu:
+            torch.cuda.set_device(self.device)
+        f = self.files[self.index.shard_path(uri, name)]
         shape, dtype, nbytes = f.meta(name)
         host = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=self.on_gpu)[:nbytes]
         if nbytes:
@@ -124,8 +127,11 @@ class PrefetchLoader:
                         self.cv.wait()
                     if self.stop:
                         return
-                for uri, name in reqs:
-                    item = self._load(uri, name)
+                for uri, name in reqs:                 # open the shard files here, not in the workers
+                    self._file(uri, name)
+                futs = [(uri, name, self.pool.submit(self._load, uri, name)) for uri, name in reqs]
+                for uri, name, fut in futs:
+                    item = fut.result()
                     with self.cv:
                         self.ready[(li, uri, name)] = item
                         self.cv.notify_all()
@@ -172,6 +178,7 @@ class PrefetchLoader:
             self.cv.notify_all()
         if self.thread is not None:
             self.thread.join(timeout=30)
+        self.pool.shutdown(wait=True)
         for f in self.files.values():
             f.close()
         self.files.clear()

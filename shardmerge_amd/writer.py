@@ -13,6 +13,8 @@ and the file is written once when the shard is complete (or at ``finalize`` /
 from __future__ import annotations
 
 import json
+import queue
+import threading
 import logging
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -75,7 +77,11 @@ class ModelWriter:
         for tensor_name, shard_name in self.base_index["weight_map"].items():
             self.shard_to_tensors.setdefault(shard_name, set()).add(tensor_name)
         self._rank = {name: i for i, name in enumerate(self.layer_order)}
-        self._pending: Dict[str, Dict[str, torch.Tensor]] = {}
+        self._pending: Dict[str, Dict[str, tuple]] = {}
+        self._lock = threading.Lock()
+        self._jobs: "queue.Queue" = queue.Queue(maxsize=2)      # at most two shards waiting to be written
+        self._thread = None
+        self._worker_error = None
         self._check_existing_shards()
 
     # -- resume ---------------------------------------------------------------------
@@ -91,38 +97,93 @@ class ModelWriter:
                     self.written_shard_layers.add((shard_name, name))
 
     # -- writing ----------------------------------------------------------------------
+    # Device results leave through a pinned buffer with an asynchronous copy on the caller's
+    # stream, and a complete shard is serialised by a background thread, so neither the
+    # device-to-host copy nor save_file() stalls the merge of the next tensors.
     def add_tensor(self, layer_name: str, tensor: torch.Tensor):
         shard_name = self.base_index["weight_map"][layer_name]
         if (shard_name, layer_name) in self.written_shard_layers:
             logger.info(f"Skipping {layer_name} as it's already in written shard {shard_name}")
             return
+        self._raise_worker_error()
         # the device -> host copy and the cast happen here, as in writer.py:133
-        self._pending.setdefault(shard_name, {})[layer_name] = tensor.detach().to("cpu").to(self.output_astype).contiguous()
-        have = {n for (s, n) in self.written_shard_layers if s == shard_name} | set(self._pending[shard_name])
+        t = tensor.detach()
+        if t.device.type == "cuda":
+            t = t.to(self.output_astype).contiguous()
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(t.device))
+            entry = (host, ev)
+        else:
+            entry = (t.to("cpu").to(self.output_astype).contiguous(), None)
+        self._pending.setdefault(shard_name, {})[layer_name] = entry
+        with self._lock:
+            have = {n for (s, n) in self.written_shard_layers if s == shard_name} | set(self._pending[shard_name])
         if have >= self.shard_to_tensors[shard_name]:
             self.flush(shard_name)
 
-    def flush(self, shard_name: str = None):
-        """Write buffered tensors (of one shard, or of all) to disk."""
+    def _raise_worker_error(self):
+        if self._worker_error is not None:
+            err, self._worker_error = self._worker_error, None
+            raise err
+
+    def _write_shard(self, name: str, fresh):
+        path = self.output_path / name
+        merged: Dict[str, torch.Tensor] = {}
+        if path.exists():                       # partial shard from an earlier run
+            with safe_open(str(path), framework="pt") as fh:
+                for k in fh.keys():
+                    merged[k] = fh.get_tensor(k)
+        for k, (t, ev) in fresh.items():
+            if ev is not None:
+                ev.synchronize()
+            merged[k] = t
+        ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
+        save_file(ordered, str(path), metadata={"format": "pt"})
+        with self._lock:
+            for k in fresh:
+                self.written_shard_layers.add((name, k))
+        logger.info(f"Wrote {len(fresh)} tensor(s) to shard {name}")
+
+    def _worker(self):
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            try:
+                self._write_shard(*job)
+            except BaseException as exc:       # surfaced by the next add_tensor()/flush()/finalize()
+                self._worker_error = exc
+            finally:
+                self._jobs.task_done()
+
+    def flush(self, shard_name: str = None, wait: bool = False):
+        """Hand buffered tensors (of one shard, or of all) to the writer thread."""
         for name in ([shard_name] if shard_name else list(self._pending)):
             fresh = self._pending.pop(name, None)
             if not fresh:
                 continue
-            path = self.output_path / name
-            merged: Dict[str, torch.Tensor] = {}
-            if path.exists():                       # partial shard from an earlier run
-                with safe_open(str(path), framework="pt") as fh:
-                    for k in fh.keys():
-                        merged[k] = fh.get_tensor(k)
-            merged.update(fresh)
-            ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
-            save_file(ordered, str(path), metadata={"format": "pt"})
-            for k in fresh:
-                self.written_shard_layers.add((name, k))
-            logger.info(f"Wrote {len(fresh)} tensor(s) to shard {name}")
+            if self._thread is None:
+                self._thread = threading.Thread(target=self._worker, name="shardmerge-writer", daemon=True)
+                self._thread.start()
+            self._jobs.put((name, fresh))
+        if wait or shard_name is None:
+            self._jobs.join()
+            self._raise_worker_error()
+
+    def wait(self):
+        """Block until every shard handed to the writer thread is on disk."""
+        self._jobs.join()
+        self._raise_worker_error()
 
     def finalize(self):
         self.flush()
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None
+        self._raise_worker_error()
         missing = [(s, n) for s, names in self.shard_to_tensors.items() for n in names
                    if (s, n) not in self.written_shard_layers]
         if missing:

@@ -87,6 +87,7 @@ def test_writer_buffers_orders_and_resumes(tmp_path):
     w.add_tensor("model.layers.0.w", torch.ones(2, 2))
     assert not (tmp_path / "o" / "s1").exists()               # shard not complete yet: nothing written
     w.add_tensor("model.embed_tokens.weight", torch.zeros(2, 2))
+    w.wait()                                                  # complete shards are written in the background
     with safe_open(str(tmp_path / "o" / "s1"), framework="pt") as f:
         assert list(f.keys()) == sorted(order[:2]) or set(f.keys()) == set(order[:2])
         assert f.get_tensor("model.layers.0.w").dtype == torch.bfloat16
