@@ -9,6 +9,11 @@ reference's shard/config.py:24-126, so existing config files work unchanged.
     output_dtype: bfloat16      # optional
     device: cuda                # optional (this build always computes on the MI355X)
     cache_dir / storage_dir / clean_cache: optional
+    merge_options:              # optional, additive: the operator's hard-coded
+      cutoff_pct: 0.08          # hyper-parameters (fast_fourier.py:84-85,238-240); defaults as there
+      cull_start_pct: 0.20
+      t_sum: 1.0
+      target_norm_offset: 1.0e-10
 """
 from __future__ import annotations
 
@@ -22,6 +27,9 @@ import torch
 import yaml
 
 _REQUIRED = ("output_base_model", "finetune_merge", "output_dir")
+# the FFT operator's hyper-parameters and the values the reference hard-codes for them
+MERGE_OPTION_DEFAULTS = {"cutoff_pct": 0.08, "cull_start_pct": 0.20, "t_sum": 1.0, "target_norm_offset": 1e-10}
+MERGE_OPTION_RANGES = {"cutoff_pct": (0.0, 1.0), "cull_start_pct": (0.0, 1.0), "t_sum": (-1e6, 1e6), "target_norm_offset": (0.0, 1e6)}
 
 
 @dataclass
@@ -52,6 +60,7 @@ class MergeConfig:
     clean_cache: bool = False
     cache_dir: str = "cache"
     storage_dir: str = "storage"
+    merge_options: Dict[str, float] = field(default_factory=dict)
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -111,4 +120,13 @@ class MergeConfig:
         if not isinstance(raw["finetune_merge"], list):
             raise click.BadParameter("finetune_merge must be a list of model URIs")
         raw["finetune_merge"] = [MergeModel(**entry) for entry in raw["finetune_merge"]]
+        opts = raw.get("merge_options") or {}
+        unknown = set(opts) - set(MERGE_OPTION_DEFAULTS)
+        if not isinstance(opts, dict) or unknown:
+            raise click.BadParameter(f"merge_options: unknown keys {sorted(unknown)}; known: {sorted(MERGE_OPTION_DEFAULTS)}")
+        for key, value in opts.items():
+            lo, hi = MERGE_OPTION_RANGES[key]
+            if not isinstance(value, (int, float)) or isinstance(value, bool) or not (lo <= float(value) <= hi):
+                raise click.BadParameter(f"merge_options.{key} must be a number in [{lo}, {hi}]")
+        raw["merge_options"] = {k: float(v) for k, v in opts.items()}
         return cls(**raw)

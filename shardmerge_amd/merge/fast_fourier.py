@@ -40,6 +40,9 @@ class FourierMerge(MergeTensorsBase):
         self.cull_start_pct = cull_start_pct
         self.cutoff_pct = 0.08          # fast_fourier.py:239
         self.t_sum = 1.0                # fast_fourier.py:238
+        # optional YAML overrides (config.merge_options); absent keys keep the reference's values
+        for key, value in (getattr(config, "merge_options", None) or {}).items():
+            setattr(self, key, float(value))
         self._engine = engine
         self.last_report = None
 

@@ -60,6 +60,26 @@ def test_config_errors(tmp_path):
 
 
 # ---- writer / index ------------------------------------------------------------------------
+def test_merge_options_are_additive_and_validated(tmp_path):
+    doc = {"output_base_model": "o/b", "finetune_merge": [{"model": "o/f", "base": "o/b"}], "output_dir": "out"}
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(doc))
+    cfg = MergeConfig.from_yaml(p)
+    assert cfg.merge_options == {}
+    m = FourierMerge(config=cfg, index_manager=LocalModelIndex(tmp_path), engine=object())
+    assert (m.cutoff_pct, m.cull_start_pct, m.t_sum, m.target_norm_offset) == (0.08, 0.20, 1.0, 1e-10)   # reference defaults
+    doc["merge_options"] = {"cutoff_pct": 0.05, "cull_start_pct": 0.1}
+    p.write_text(yaml.safe_dump(doc))
+    cfg = MergeConfig.from_yaml(p)
+    m = FourierMerge(config=cfg, index_manager=LocalModelIndex(tmp_path), engine=object())
+    assert (m.cutoff_pct, m.cull_start_pct, m.t_sum) == (0.05, 0.1, 1.0)
+    for bad in ({"cutoff": 0.1}, {"cutoff_pct": 2.0}, {"t_sum": "x"}):
+        doc["merge_options"] = bad
+        p.write_text(yaml.safe_dump(doc))
+        with pytest.raises(click.BadParameter):
+            MergeConfig.from_yaml(p)
+
+
 def test_shard_layer_numbers():
     mk = lambda n: ShardLayer(0, "s", n, False).layer_number
     assert mk("model.embed_tokens.weight") == INPUT_LAYER
