@@ -1444,6 +1444,7 @@ struct ScanParams {
     int init;                   // 1: first level, start from rank_init / empty prefix
     unsigned long long rank_init;
     unsigned long long* zero_also; int zero_count;   // further histogram words to clear (fast path: all levels)
+    uint32_t* zero_u32; int zero_u32_count;          // and 32-bit words (the candidate-list counters)
 };
 
 // single work-group of 256 threads
@@ -1491,6 +1492,7 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
     ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) p.hist[b] = 0;
         if (p.zero_also) for (int b = tid; b < p.zero_count; b += nt) p.zero_also[b] = 0;
+        if (p.zero_u32) for (int b = tid; b < p.zero_u32_count; b += nt) p.zero_u32[b] = 0u;
     });
 }
 
@@ -1560,6 +1562,7 @@ struct SlerpConstParams {
     const float* thr;           // device scalar or null (-> 0)
     float t;
     BlendConsts* out;
+    uint32_t* zero_u32; int zero_u32_count;  // candidate-list counters to clear for the next selection (or null)
 };
 
 // one work-group: sum the partials (fixed order per thread, then the block
@@ -1579,6 +1582,7 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
             a0 += src[4 * i]; a1 += src[4 * i + 1];
             a2 += src[4 * i + 2]; a3 += src[4 * i + 3];
         }
+        if (p.zero_u32 && tid < p.zero_u32_count) p.zero_u32[tid] = 0u;
         s.red[0] = a0; s.red[1] = a1; s.red[2] = a2; s.red[3] = a3;
     });
     ex.template block_sum<4>(st, [&](const double* tot) {
@@ -1602,6 +1606,36 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
 }
 
 // sum [n][2] double partials into out[2] (norm^2 of the two signals of F1 / combine)
+// Results the host waits for are written by the last small kernel straight into a host-mapped
+// "mailbox" (pinned, device-visible): a stream synchronisation replaces the copy kernels and
+// staging of hipMemcpyAsync into pageable memory.
+struct Mailbox {
+    double norm2[2];            // k_sum_partials
+    uint32_t flags[12];         // NaN/Inf flags [0..7] + candidate counters [8..11] (k_publish)
+    float thr[4];               // d_thr(0..3)
+    BlendConsts consts;
+};
+struct PublishParams {
+    const uint32_t* flags;      // device flags + counters (12 words)
+    const float* thr;
+    const BlendConsts* consts;
+    Mailbox* mail;
+    uint32_t* zero_flags;       // when set: the 12 flag words are cleared after the copy
+};
+template <class Ex>
+SM_HD void k_publish(Ex& ex, const PublishParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid < 12) {
+            p.mail->flags[tid] = p.flags[tid];
+            if (p.zero_flags) p.zero_flags[tid] = 0u;
+        }
+        if (tid < 4) p.mail->thr[tid] = p.thr[tid];
+        if (tid == 0) p.mail->consts = *p.consts;
+    });
+}
+
 struct SumPartialsParams { const double* partials; int nparts; double* out; };
 template <class Ex>
 SM_HD void k_sum_partials(Ex& ex, const SumPartialsParams& p) {

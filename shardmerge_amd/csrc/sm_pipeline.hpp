@@ -103,6 +103,7 @@ inline bool plan_matches(const FftPlanDev& pl) {
 }
 SM_KERNEL_TAG(KF2R1, F2Params, "f2_cols_fwd", k_f2_r1(ex, p))
 SM_KERNEL_TAG(KI1R1, I1Params, "i1_cols_inv", k_i1_r1(ex, p))
+SM_KERNEL_TAG(KPublish, PublishParams, "publish", k_publish(ex, p))
 SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
 SM_KERNEL_TAG(KSelect2, Select2Params, "select_lvl2", k_select2(ex, p))
@@ -190,6 +191,7 @@ class Pipeline {
     ~Pipeline() {
         for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
         for (Buffer* b : {&cand_, &t1_, &planes_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
     }
 
@@ -289,6 +291,8 @@ class Pipeline {
         if (!small_.p) {
             if ((rc = ensure(small_, SMALL_BYTES))) return rc;
             be.memset(small_.p, 0, SMALL_BYTES, stream);
+            if (!mail_) mail_ = (Mailbox*)be.alloc_host(sizeof(Mailbox));
+            if (!mail_) return fail(SMHIP_ERR_NOMEM, "host mailbox");
         }
         return SMHIP_OK;
     }
@@ -394,11 +398,10 @@ class Pipeline {
     }
     void read_norms(int grid, double& na, double& nb) {
         SumPartialsParams sp;
-        sp.partials = d_part(); sp.nparts = grid; sp.out = d_norm2();
+        sp.partials = d_part(); sp.nparts = grid; sp.out = mail_->norm2;     // host-mapped: no copy, one sync
         be.template launch<KSumPartials>(1, 256, LDS_SCRATCH_FLOATS * 4, sp, stream);
-        double two[2];
-        be.d2h(two, d_norm2(), sizeof two, stream);
-        na = std::sqrt(two[0]); nb = std::sqrt(two[1]);
+        be.sync(stream);
+        na = std::sqrt(mail_->norm2[0]); nb = std::sqrt(mail_->norm2[1]);
     }
 
     int run_f2(const Geo& g, float scale0, float scale1, int swap, bool hist) {
@@ -448,6 +451,7 @@ class Pipeline {
         const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256) * 4;
         ScanParams s;
         s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out; s.zero_also = nullptr; s.zero_count = 0;
+        s.zero_u32 = nullptr; s.zero_u32_count = 0;
         if (!level1_done) { h.level = 1; be.template launch<KHist>(hgrid, 256, hlds, h, stream); }
         if (nparts_out) *nparts_out = 0;
         if (safe_select) {
@@ -461,7 +465,7 @@ class Pipeline {
             }
             return;
         }
-        be.memset(d_candctr(), 0, 12, stream);             // n_keys, n_pairs, overflow (not the sticky word)
+        // (the list counters n_keys, n_pairs, overflow are zero here: the final scan clears them)
         Select2Params q;
         q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0);
         q.hist1 = d_hist(); q.rank = rank; q.hist = d_hist2();
@@ -478,6 +482,9 @@ class Pipeline {
 
         s.hist = d_hist3(); s.sel = d_sel(1); s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = 1; s.init = 0;
         s.zero_also = d_hist(); s.zero_count = HIST1_BINS + HIST_LO_BINS;      // hist1 and hist2 (hist3 is s.hist)
+        // the list counters are cleared by the last kernel that reads them: this scan, or (when
+        // the slerp sums come from the lists) slerp_consts after the candidate reduction
+        if (!q.fuse_reduce) { s.zero_u32 = d_candctr(); s.zero_u32_count = 3; }   // not the sticky overflow word
         be.template launch<KScan>(1, 256, scan_lds, s, stream);
 
         if (q.fuse_reduce) {
@@ -505,7 +512,9 @@ class Pipeline {
         SlerpConstParams c;
         c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
         c.thr = have_thr ? d_thr(0) : nullptr; c.t = t; c.out = d_consts();
+        c.zero_u32 = nullptr; c.zero_u32_count = 0;
         if (fused_parts > 0) {
+            c.zero_u32 = d_candctr(); c.zero_u32_count = 3;
             c.partials = d_part(); c.nparts = fused_parts;
         } else {
             ReduceParams r;
@@ -577,12 +586,21 @@ class Pipeline {
         if (grid_out) *grid_out = grid;
     }
 
-    void read_blend_info(smhip_blend_info* info, bool have_cut, bool have_cull, bool have_consts) {
+    // flags, thresholds and blend constants -> mailbox, one tiny kernel and one sync
+    void publish(bool zero_flags) {
+        PublishParams pp;
+        pp.flags = d_flags(); pp.thr = d_thr(0); pp.consts = d_consts(); pp.mail = mail_;
+        pp.zero_flags = zero_flags ? d_flags() : nullptr;
+        be.template launch<KPublish>(1, 64, LDS_SCRATCH_FLOATS * 4, pp, stream);
+        be.sync(stream);
+        if (zero_flags) flags_clean_ = true;
+    }
+    void read_blend_info(smhip_blend_info* info, bool have_cut, bool have_cull, bool have_consts, bool published = false) {
         if (!info) return;
-        BlendConsts c;
+        if (!published) publish(false);
+        const BlendConsts c = mail_->consts;
         float thr[4];
-        be.d2h(&c, d_consts(), sizeof c, stream);
-        be.d2h(thr, d_thr(0), sizeof thr, stream);
+        for (int i = 0; i < 4; ++i) thr[i] = mail_->thr[i];
         info->cutoff_threshold = have_cut ? thr[0] : 0.0;
         info->cull_threshold = have_cull ? thr[1] : 0.0;
         info->dot = have_consts ? c.dot : 0.0;
@@ -694,11 +712,19 @@ class Pipeline {
     }
 
     // NaN/Inf flags and, right behind them, the candidate-list counters with their sticky overflow word
-    void clear_flags() { be.memset(d_flags(), 0, 48, stream); overflow_seen_ = false; }
+    // (every check_flags() leaves the device flags cleared; a memset is needed only after a
+    // call that ended without one)
+    void clear_flags() {
+        if (!small_.p && reserve(1, 1)) return;      // first call on this context: the small block and the mailbox
+        if (!flags_clean_) be.memset(d_flags(), 0, 48, stream);
+        flags_clean_ = false;
+        overflow_seen_ = false;
+    }
     // did a candidate list overflow since clear_flags()?  (sticky word, read with a sync)
     bool select_overflowed() {
         uint32_t v = 0;
-        be.d2h(&v, d_candctr() + 3, sizeof v, stream);
+        publish(false);
+        v = mail_->flags[11];
         return v != 0;
     }
     // Run `body` (a whole API call); if one of its selections overflowed its candidate
@@ -716,7 +742,8 @@ class Pipeline {
 
     int check_flags(bool ifft_stage, bool final_stage, uint32_t* nan_ifft = nullptr, uint32_t* nan_final = nullptr) {
         uint32_t f[12];                      // flags[8] + candidate counters[4]
-        be.d2h(f, d_flags(), sizeof f, stream);
+        publish(true);
+        for (int i = 0; i < 12; ++i) f[i] = mail_->flags[i];
         if (f[11] && !safe_select) { overflow_seen_ = true; return SMHIP_OK; }   // with_select_retry() redoes the call
         if (nan_ifft) *nan_ifft = f[0];
         if (nan_final) *nan_final = f[2];
@@ -871,6 +898,8 @@ class Pipeline {
 
         std::vector<char> inter_busy(inter_.size(), 0);
         int step = 0;
+        int deferred_step = -1;
+        bool deferred_cut = false, deferred_cull = false;
         while (stack.size() > 1) {
             const int m = (int)stack.size();
             std::vector<std::pair<int, int>> pairs;
@@ -965,7 +994,11 @@ class Pipeline {
                             SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
                             run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
                         }
-                        read_blend_info(&info, d.cutoff_pct > 0, have_cull, true);
+                        if (last_round) {      // read with the flags at the end of the layer: one sync less
+                            deferred_step = step; deferred_cut = d.cutoff_pct > 0; deferred_cull = have_cull;
+                        } else {
+                            read_blend_info(&info, d.cutoff_pct > 0, have_cull, true);
+                        }
                     }
                 }
                 if (step < SMHIP_MAX_PAIRS) { rp.step_branch[step] = branch; rp.step_info[step] = info; }
@@ -998,7 +1031,10 @@ class Pipeline {
             read_norms(grid, nm, dummy);
             rp.merged_delta_norm = nm;
         }
-        return check_flags(true, true, &rp.nan_ifft, &rp.nan_final);
+        rc = check_flags(true, true, &rp.nan_ifft, &rp.nan_final);
+        if (deferred_step >= 0 && deferred_step < SMHIP_MAX_PAIRS)
+            read_blend_info(&rp.step_info[deferred_step], deferred_cut, deferred_cull, true, /*published=*/true);
+        return rc;
     }
 
     // ---- transforms for the function-level API -----------------------------------------
@@ -1101,6 +1137,8 @@ class Pipeline {
     Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
     uint32_t cap_keys_ = 0, cap_pairs_ = 0;
     bool overflow_seen_ = false;
+    bool flags_clean_ = false;
+    Mailbox* mail_ = nullptr;
     std::vector<Buffer> inter_;
     std::vector<double> host_part_;
 };

@@ -57,6 +57,15 @@ struct HipBackend {
         return p;
     }
     void free(void* p) { check(hipFree(p), "hipFree"); }
+    // pinned host memory the device can write (same pointer on both sides)
+    void* alloc_host(size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e != hipSuccess) { check(e, "hipHostMalloc"); return nullptr; }
+        ::memset(p, 0, n);
+        return p;
+    }
+    void free_host(void* p) { check(hipHostFree(p), "hipHostFree"); }
     void memset(void* p, int v, size_t n, void* s) { check(hipMemsetAsync(p, v, n, (hipStream_t)s), "hipMemsetAsync"); }
     void sync(void* s) { check(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize"); }
     void d2h(void* dst, const void* src, size_t n, void* s) {

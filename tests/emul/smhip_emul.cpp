@@ -54,6 +54,8 @@ struct HostBackend {
     std::string error() const { return ""; }
     void* alloc(size_t n) { void* p = nullptr; if (posix_memalign(&p, 256, n ? n : 16)) return nullptr; ::memset(p, 0xCD, n); return p; }
     void free(void* p) { ::free(p); }
+    void* alloc_host(size_t n) { void* p = calloc(1, n ? n : 16); return p; }
+    void free_host(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n, void*) { ::memset(p, v, n); }
     void sync(void*) {}
     void d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); }
