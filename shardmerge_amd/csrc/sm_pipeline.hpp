@@ -399,7 +399,7 @@ class Pipeline {
     void read_norms(int grid, double& na, double& nb) {
         SumPartialsParams sp;
         sp.partials = d_part(); sp.nparts = grid; sp.out = mail_->norm2;     // host-mapped: no copy, one sync
-        be.template launch<KSumPartials>(1, 256, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
         be.sync(stream);
         na = std::sqrt(mail_->norm2[0]); nb = std::sqrt(mail_->norm2[1]);
     }
