@@ -123,7 +123,10 @@ int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf
                       smhip_layer_report* report, void* stream);
 
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
- *      lists (0 = default) so that the overflow fallback can be exercised. -------- */
+ *      lists (0 = default) so that the overflow fallback can be exercised;
+ *      "sel_chunks" sets the steps per thread of the level-2 selection pass and
+ *      "sel_flush_always" flushes its staged candidates after every round (the
+ *      mid-stream flush that only very large tensors reach otherwise). --------------- */
 int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
 
 /* ---- profiling: per-kernel device time measured with HIP events on the

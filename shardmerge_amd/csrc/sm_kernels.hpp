@@ -1159,6 +1159,7 @@ struct Select2Params {
     int fuse_reduce;                    // needs Y: X = Re a, Y = Re b
     double* partials;                   // [grid][4] when fuse_reduce
     int chunks;
+    int flush_always;          // test hook: flush the staged candidates after every round
 };
 
 template <class Ex>
@@ -1281,7 +1282,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     // flush when the staging area is more than half full (the counts are the same for every
     // thread after the barrier, so the branch is uniform), and at the end
     const bool last_round = r1 >= p.chunks;
-    if (!last_round && lctl[0] <= (uint32_t)STAGE_KEYS / 2 && lctl[1] <= (uint32_t)STAGE_PAIRS / 2) continue;
+    if (!last_round && !p.flush_always && lctl[0] <= (uint32_t)STAGE_KEYS / 2 && lctl[1] <= (uint32_t)STAGE_PAIRS / 2) continue;
     ex.each(st, [&](int tid, EmptyState&) {
         if (tid == 0) {
             uint32_t nk = lctl[0], np = lctl[1];

@@ -185,6 +185,8 @@ class Pipeline {
     std::string err;
     void* stream = nullptr;
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
+    uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
+    bool debug_flush_always = false;  // test hook: flush staged candidates after every round
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
 
     explicit Pipeline(int device) : be(device) {}
@@ -470,7 +472,8 @@ class Pipeline {
         q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0);
         q.hist1 = d_hist(); q.rank = rank; q.hist = d_hist2();
         q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part();
-        q.chunks = pick_chunks((total + 3) / 4, 256, 8, 4);   // 4 resident work-groups per CU (113 VGPRs): one round, no tail
+        q.flush_always = debug_flush_always ? 1 : 0;
+        q.chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, 4);   // 4 resident work-groups per CU (113 VGPRs): one round, no tail
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
         while ((size_t)(grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
         const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);

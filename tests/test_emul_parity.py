@@ -96,6 +96,31 @@ def test_candidate_list_overflow_falls_back(engine, golden):
     assert rep1.n_slerp == rep0.n_slerp and rep1.s01 == pytest.approx(rep0.s01, rel=1e-9)
 
 
+def test_selection_rounds_and_midstream_flush(engine, golden):
+    """The level-2 selection pass streams in rounds and flushes its staged candidates to the
+    global lists between rounds when the stage fills up (only 100 M-element tensors get there
+    by themselves): force many rounds and a flush after each, the result must not change."""
+    case = [c for c in gi.PAIR_CASES if c["id"] == "pair_256_mix"][0]
+    a, b = gi.pair_input(case)
+    kw = dict(b=case["b"], t_sum=case["t_sum"], cutoff_pct=case["cutoff"], cull_pct=case["cull"])
+    ref, _, _, rep0 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
+    engine.ctx.debug_option("sel_chunks", 64)           # one work-group, 4 rounds of 16 steps
+    engine.ctx.debug_option("sel_flush_always", 1)
+    engine.ctx.profile(True)
+    engine.ctx.profile_reset()
+    try:
+        out, _, _, rep1 = engine.merge_tensors_fft2_slerp(a, b, case["t"], **kw)
+        launches = engine.ctx.profile_table()
+    finally:
+        engine.ctx.debug_option("sel_chunks", 0)
+        engine.ctx.debug_option("sel_flush_always", 0)
+        engine.ctx.profile(False)
+    assert "select_hist" not in launches                                   # still the fast path
+    assert rep1.cutoff_threshold == rep0.cutoff_threshold and rep1.cull_threshold == rep0.cull_threshold
+    assert rep1.n_slerp == rep0.n_slerp and rep1.s01 == pytest.approx(rep0.s01, rel=1e-9)
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
 def test_heavy_ties(engine):
     """Quantised inputs give spectra with many exactly equal magnitudes (and exact
     zeros): the order statistics must still be the reference's."""

@@ -215,6 +215,29 @@ def test_large_tensors_take_the_fast_selection_path(engine, shape):
     torch.cuda.empty_cache()
 
 
+def test_midstream_candidate_flush_on_device(engine):
+    """Same layer with the selection pass forced into many rounds and a flush after each
+    (what a 235 M-element Llama-3-70B tensor does by itself): identical thresholds, class
+    counts and output."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shape = (4096, 2048)
+    base = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g, device="cuda") * s).to(torch.bfloat16) for s in (0.002, 0.003)]
+    out0, rep0 = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)
+    engine.ctx.debug_option("sel_chunks", 96)
+    engine.ctx.debug_option("sel_flush_always", 1)
+    try:
+        out1, rep1 = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)
+    finally:
+        engine.ctx.debug_option("sel_chunks", 0)
+        engine.ctx.debug_option("sel_flush_always", 0)
+    i0, i1 = rep0.infos[0], rep1.infos[0]
+    assert i0.cutoff_threshold == i1.cutoff_threshold and i0.cull_threshold == i1.cull_threshold
+    assert i0.n_slerp == i1.n_slerp
+    assert (out0.float() - out1.float()).abs().max().item() <= 2 ** -7 * out0.float().abs().max().item()   # at most a bf16 ulp
+    assert (out0 != out1).float().mean().item() < 1e-3
+
+
 def test_cli_end_to_end_on_device(tmp_path, golden):
     """`python -m shard merge CONFIG` (device: cuda) on the tiny on-disk model of G8:
     files, index, README and tensors against the reference CLI's output."""
