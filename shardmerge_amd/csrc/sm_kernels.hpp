@@ -450,6 +450,22 @@ struct F2Params {
 // BINS adjacent bin columns per work-group (2*BINS transforms, 2*BINS*T threads): the
 // row segment a work-group reads is BINS*16 bytes wide, so short columns get full
 // 128-byte segments (BINS = 8) and 8192-long ones 32 bytes.
+// Layout and grouping rules shared with the host (sm_pipeline.hpp: t1_interleave(), run_f2()).
+// For a static plan the column length is known, so both are compile-time constants and the
+// kernel contains one variant only (the union of all variants cost ~10 % through register
+// allocation alone).
+#ifndef SM_T1_ILV
+#define SM_T1_ILV 2
+#endif
+#ifndef SM_T1_ILV_MIN_ROWS
+#define SM_T1_ILV_MIN_ROWS 8192
+#endif
+#ifndef SM_F2_MAX_THREADS
+#define SM_F2_MAX_THREADS 512
+#endif
+SM_HD constexpr int t1_interleave_rows(int R) { return R >= SM_T1_ILV_MIN_ROWS ? SM_T1_ILV : 1; }
+SM_HD constexpr int f2_nsig_for(int T) { return (2 * T <= SM_F2_MAX_THREADS) ? 2 : 1; }
+
 template <class P, int BINS, class Ex>
 SM_HD void k_f2(Ex& ex, const F2Params& p) {
     typename Ex::template State<FftState> st;
@@ -458,7 +474,8 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const FftPlanDev& pl = p.plan;
     const int T = plan_T<P>(pl), R = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
-    const int ng = p.nsig;
+    const int ng = P::is_static ? f2_nsig_for(T) : p.nsig;              // compile-time for static plans
+    const int ilv = P::is_static ? t1_interleave_rows(R) : p.ilv;
     const int bid = ex.bid();
     // 8/BINS work-groups share a 128-byte line of T1 (16 bytes per bin)
     // (one signal per work-group, T = 1024: the 16 work-groups of a line - 8 bins x 2 signals)
@@ -487,8 +504,8 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                     s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
                 }
             };
-            if (p.ilv == 4) load_rows(std::integral_constant<int, 4>{});
-            else if (p.ilv == 2) load_rows(std::integral_constant<int, 2>{});
+            if (ilv == 4) load_rows(std::integral_constant<int, 4>{});
+            else if (ilv == 2) load_rows(std::integral_constant<int, 2>{});
             else load_rows(std::integral_constant<int, 1>{});
         } else {
 #pragma unroll
@@ -496,7 +513,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                 const int n = tid + q * T;
                 float re = 0.f, im = 0.f;
                 if (n < R) {
-                    const cf2* src = (const cf2*)(p.t1 + ((size_t)(n / p.ilv) * p.pitch4 + kbase) * p.ilv + n % p.ilv) + slot0;
+                    const cf2* src = (const cf2*)(p.t1 + ((size_t)(n / ilv) * p.pitch4 + kbase) * ilv + n % ilv) + slot0;
                     re = src->x; im = src->y;
                 }
                 s.xr[q] = re; s.xi[q] = im;
@@ -520,8 +537,8 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                         if (n < R) { la[lpad(n)] = x[2 * q]; la[LF + lpad(n)] = x[2 * q + 1]; }
                     }
                 };
-                if (p.ilv == 4) scatter_rows(std::integral_constant<int, 4>{});
-                else if (p.ilv == 2) scatter_rows(std::integral_constant<int, 2>{});
+                if (ilv == 4) scatter_rows(std::integral_constant<int, 4>{});
+                else if (ilv == 2) scatter_rows(std::integral_constant<int, 2>{});
                 else scatter_rows(std::integral_constant<int, 1>{});
             } else {
 #pragma unroll

@@ -278,7 +278,7 @@ class Pipeline {
 #ifndef SM_T1_ILV_MIN_ROWS
 #define SM_T1_ILV_MIN_ROWS 8192
 #endif
-    static int t1_interleave(int R) { return R >= SM_T1_ILV_MIN_ROWS ? SM_T1_ILV : 1; }
+    static int t1_interleave(int R) { return t1_interleave_rows(R); }
     static constexpr int MAXGRID_PART = 1 << 20;
     int reserve(int R, int C, bool full = false) {
         const Geo g = geo(R, C, full);
@@ -422,7 +422,7 @@ class Pipeline {
         // A and B of a bin in one work-group up to 512 threads; longer columns (T = 512: 14336,
         // 16384 rows) run one signal per work-group: two independent 512-thread groups per CU
         // overlap their phases, which beats the 16-byte reads of one lock-step 1024-thread group
-        p.nsig = (2 * p.plan.T <= SM_F2_MAX_THREADS) ? 2 : 1;
+        p.nsig = f2_nsig_for(p.plan.T);
         p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
         p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
         p.hist = hist ? d_hist() : nullptr;
