@@ -180,6 +180,7 @@ SM_HD uint32_t weight_at(const WeightRanges& w, size_t i) {
 }
 
 struct EmptyStateF { double red[2]; };
+struct NormsState { double red[16]; };
 
 struct FftState {
     float xr[EREG];
@@ -1628,7 +1629,7 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
 // "mailbox" (pinned, device-visible): a stream synchronisation replaces the copy kernels and
 // staging of hipMemcpyAsync into pageable memory.
 struct Mailbox {
-    double norm2[2];            // k_sum_partials
+    double norm2[16];           // k_sum_partials (2) / k_delta_norms' reduction (up to 16 models)
     uint32_t flags[12];         // NaN/Inf flags [0..7] + candidate counters [8..11] (k_publish)
     float thr[4];               // d_thr(0..3)
     BlendConsts consts;
@@ -1753,6 +1754,87 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
 // =====================================================================
 // elementwise spatial kernels (deltas, norms, add branch, K=1 finish)
 // =====================================================================
+// ||finetune_i - base_i||^2 of every model in ONE pass (K >= 3 needs all norms before the
+// first pairing): a base tensor shared by several models is loaded once per octet.
+// 16-bit inputs, n % 8 == 0, 16-byte aligned pointers (the host falls back to k_combine otherwise).
+constexpr int NORMS_MAX = 16;       // row length of the partials / mailbox
+constexpr int NORMS_K = 8;          // models one launch handles
+struct DeltaNormsParams {
+    int k;                           // <= NORMS_K
+    const void* ft[NORMS_K];
+    const void* ubase[2];            // the (at most two) distinct base tensors
+    int base_of[NORMS_K];            // model -> 0 / 1
+    int dtype;
+    size_t n;
+    int chunks;                      // octets per thread
+    double* partials;                // [grid][NORMS_MAX]
+};
+template <class Ex>
+SM_HD void k_delta_norms(Ex& ex, const DeltaNormsParams& p) {
+    typename Ex::template State<NormsState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t noct = p.n / 8;
+    const u32x4* b0 = (const u32x4*)p.ubase[0];
+    const u32x4* b1 = (const u32x4*)(p.ubase[1] ? p.ubase[1] : p.ubase[0]);
+    ex.each(st, [&](int tid, NormsState& s) {
+        double acc[NORMS_K];
+#pragma unroll
+        for (int i = 0; i < NORMS_K; ++i) acc[i] = 0.0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t oi = start + (size_t)q * nt + tid;
+            if (oi >= noct) break;
+            u32x4 rf[NORMS_K];
+            const u32x4 r0 = b0[oi], r1 = b1[oi];
+#pragma unroll
+            for (int i = 0; i < NORMS_K; ++i) rf[i] = ((const u32x4*)p.ft[i < p.k ? i : 0])[oi];
+            float v0[8], v1[8];
+            decode16x8(r0, p.dtype, v0);
+            decode16x8(r1, p.dtype, v1);
+#pragma unroll
+            for (int i = 0; i < NORMS_K; ++i) {
+                float vf[8];
+                decode16x8(rf[i], p.dtype, vf);
+                const bool second = p.base_of[i] != 0;
+                float ps = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = vf[e] - (second ? v1[e] : v0[e]);
+                    ps += d * d;
+                }
+                if (i < p.k) acc[i] += ps;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NORMS_MAX; ++i) s.red[i] = i < NORMS_K ? acc[i < NORMS_K ? i : 0] : 0.0;
+    });
+    ex.template block_sum<NORMS_MAX>(st, [&](const double* tot) {
+        for (int i = 0; i < NORMS_MAX; ++i) p.partials[(size_t)ex.bid() * NORMS_MAX + i] = tot[i];
+    });
+}
+struct SumNParams { const double* partials; int nparts; double* out; };
+template <class Ex>
+SM_HD void k_sum_partials_n(Ex& ex, const SumNParams& p) {
+    typename Ex::template State<NormsState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, NormsState& s) {
+        double a[NORMS_MAX];
+#pragma unroll
+        for (int i = 0; i < NORMS_MAX; ++i) a[i] = 0.0;
+        for (int r = tid; r < p.nparts; r += nt) {
+#pragma unroll
+            for (int i = 0; i < NORMS_MAX; ++i) a[i] += p.partials[(size_t)r * NORMS_MAX + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NORMS_MAX; ++i) s.red[i] = a[i];
+    });
+    ex.template block_sum<NORMS_MAX>(st, [&](const double* tot) {
+        for (int i = 0; i < NORMS_MAX; ++i) p.out[i] = tot[i];
+    });
+}
+
 struct CombineParams {
     SigDesc a, b;               // b.x may be null
     float ca, cb;               // out = ca*a + cb*b

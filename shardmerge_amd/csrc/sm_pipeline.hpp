@@ -112,6 +112,8 @@ SM_KERNEL_TAG(KReduceCand, ReduceCandParams, "slerp_reduce_cand", k_reduce_cand(
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
 SM_KERNEL_TAG(KSlerpConsts, SlerpConstParams, "slerp_consts", k_slerp_consts(ex, p))
 SM_KERNEL_TAG(KSumPartials, SumPartialsParams, "sum_partials", k_sum_partials(ex, p))
+SM_KERNEL_TAG(KDeltaNorms, DeltaNormsParams, "delta_norms", k_delta_norms(ex, p))
+SM_KERNEL_TAG(KSumPartialsN, SumNParams, "sum_partials", k_sum_partials_n(ex, p))
 SM_KERNEL_TAG(KBlend, BlendParams, "blend", k_blend(ex, p))
 SM_KERNEL_TAG(KCombine, CombineParams, "combine", k_combine(ex, p))
 SM_KERNEL_TAG(KExpand, ExpandParams, "expand_full", k_expand(ex, p))
@@ -825,6 +827,35 @@ class Pipeline {
         double norm;        // ||.||_2 if known, else < 0
     };
 
+    // all delta norms in one pass (16-bit inputs, at most two distinct bases, aligned, n % 8 == 0);
+    // false: not applicable, the caller takes the pairwise path
+    bool run_delta_norms(const smhip_layer_desc& d, size_t n, std::vector<Slot>& stack) {
+        if (d.k > NORMS_K || d.in_dtype == DT_F32 || (n % 8) != 0) return false;
+        DeltaNormsParams p;
+        p.k = d.k; p.dtype = d.in_dtype; p.n = n;
+        p.ubase[0] = p.ubase[1] = nullptr;
+        int nb = 0;
+        for (int i = 0; i < NORMS_K; ++i) { p.ft[i] = d.finetune[i < d.k ? i : 0]; p.base_of[i] = 0; }
+        for (int i = 0; i < d.k; ++i) {
+            if (!d.base[i] || !aligned16(d.base[i]) || !aligned16(d.finetune[i])) return false;
+            int j = 0;
+            while (j < nb && p.ubase[j] != d.base[i]) ++j;
+            if (j == nb) { if (nb == 2) return false; p.ubase[nb++] = d.base[i]; }
+            p.base_of[i] = j;
+        }
+        p.chunks = pick_chunks(n / 8, 256, 4, 8);
+        int grid = stream_grid(n / 8, 256, p.chunks);
+        while ((size_t)grid * NORMS_MAX > PART_DOUBLES) { p.chunks *= 2; grid = stream_grid(n / 8, 256, p.chunks); }
+        p.partials = d_part();
+        be.template launch<KDeltaNorms>(grid, 256, LDS_SCRATCH_FLOATS * 4, p, stream);
+        SumNParams sp;
+        sp.partials = d_part(); sp.nparts = grid; sp.out = mail_->norm2;
+        be.template launch<KSumPartialsN>(1, 256, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        be.sync(stream);
+        for (int i = 0; i < d.k; ++i) stack[i].norm = std::sqrt(mail_->norm2[i]);
+        return true;
+    }
+
     int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
         return with_select_retry([&] { return merge_layer_once(d, out_bf16, delta_out, rep); });
     }
@@ -874,15 +905,17 @@ class Pipeline {
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
         } else {
-            SigDesc none{nullptr, nullptr, DT_F32, 1.f};
-            for (int i = 0; i < d.k; i += 2) {
-                int grid;
-                const bool two = i + 1 < d.k;
-                run_combine(stack[i].sig, two ? stack[i + 1].sig : none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
-                double na, nb;
-                read_norms(grid, na, nb);
-                stack[i].norm = na;
-                if (two) stack[i + 1].norm = nb;
+            if (!run_delta_norms(d, n, stack)) {
+                SigDesc none{nullptr, nullptr, DT_F32, 1.f};
+                for (int i = 0; i < d.k; i += 2) {
+                    int grid;
+                    const bool two = i + 1 < d.k;
+                    run_combine(stack[i].sig, two ? stack[i + 1].sig : none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
+                    double na, nb;
+                    read_norms(grid, na, nb);
+                    stack[i].norm = na;
+                    if (two) stack[i + 1].norm = nb;
+                }
             }
         }
         double mean = 0;
