@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the device: K=2 layers of random supported shapes, noise levels
+and alphas against the exact-norm oracle (CPU), through the C ABI.  Sizes stay small enough
+for the oracle to finish in a fraction of a second each.
+    python tools/fuzz_gpu.py [cases] [seed]"""
+import math
+import random
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from oracle import spectral_oracle as so
+from shardmerge_amd.engine import get_engine
+from tests import parity_checks as pc
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+eng = get_engine("cuda")
+
+
+def supported(nmax):
+    out = []
+    for n in range(2, nmax + 1):
+        m = n
+        for p in (2, 3, 5, 7, 11, 13):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            out.append(n)
+    return out
+
+
+LENS = supported(4096)
+worst = (0, None)
+bad = 0
+for ci in range(cases):
+    while True:
+        rows = rng.choice(LENS + [1] * 40)
+        cols = rng.choice(LENS)
+        if 64 <= rows * cols <= 1 << 21:
+            break
+    k = 2
+    g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    shape = (cols,) if rows == 1 else (rows, cols)
+    base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+    sig = [10 ** rng.uniform(-3.2, -2.0) for _ in range(k)]
+    fts = [(base.float() + torch.randn(shape, generator=g) * s).to(torch.bfloat16) for s in sig]
+    alphas = [rng.uniform(0.05, 1.0) for _ in range(k)]
+    trx = so.LayerTrace()
+    with so.exact_norms():
+        refx = so.merge_layer(fts, [base] * k, alphas, base, trace=trx)
+    out, rep, delta = eng.merge_layer([t.cuda() for t in fts], [base.cuda()] * k, alphas, base.cuda(), want_delta=True)
+    ok = rep.branches == trx.branches
+    d_total, d_resid = pc.spectral_residual(delta.cpu().reshape(rows, cols) if rows > 1 else delta.cpu().reshape(1, cols),
+                                            trx.merged_delta.reshape(rows, cols) if rows > 1 else trx.merged_delta.reshape(1, cols))
+    n = rows * cols
+    tol_total = 10.0 / math.sqrt(n) + 1e-5
+    out_err = so.rel_err(out.cpu().float(), refx.float())
+    fine = ok and d_resid < 5e-5 and d_total < tol_total and out_err < max(2e-3, 0.05 * tol_total)   # tiny tensors: tie-bin floor ~ 1/sqrt(n)
+    tag = "ok " if fine else "BAD"
+    if not fine:
+        bad += 1
+    if d_resid > worst[0]:
+        worst = (d_resid, (rows, cols))
+    print(f"{tag} [{rows}x{cols}] sig={sig[0]:.1e},{sig[1]:.1e} branches={rep.branches} vs {trx.branches} "
+          f"delta total {d_total:.2e} (tol {tol_total:.1e}) beyond-ties {d_resid:.2e} out {out_err:.2e}")
+print(f"{cases} cases, {bad} bad; worst beyond-tie residual {worst[0]:.2e} at {worst[1]}")
+sys.exit(1 if bad else 0)
