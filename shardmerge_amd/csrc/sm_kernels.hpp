@@ -749,40 +749,39 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             float* o = comp_of<comp>(s);
-            // thread handles rows r = tid + q*(S*T); needs every group's value
+            // thread handles the row PAIRS m = tid + j*(S*T) (rows 2m, 2m+1) and needs every
+            // group's value: slot (2j + par)*S + g
 #pragma unroll
-            for (int q = 0; q < EMAX / S; ++q) {
-                const int r = tid + q * S * T;
-                if (r < R) {
+            for (int j = 0; j < EMAX / (2 * S); ++j) {
+                const int m = tid + j * S * T;
 #pragma unroll
-                    for (int g = 0; g < S; ++g) o[q * S + g] = lds[g * LF + lpad(r)];
+                for (int par = 0; par < 2; ++par) {
+                    const int r = 2 * m + par;
+                    if (r < R) {
+#pragma unroll
+                        for (int g = 0; g < S; ++g) o[(2 * j + par) * S + g] = lds[g * LF + lpad(r)];
+                    }
                 }
             }
         });
 
+    // G is stored in row pairs, [R/2][pitchG][2] float2: the inverse row pass takes rows
+    // (2m, 2m+1) as one complex transform, and this pass writes 16 contiguous bytes per
+    // (pair, bin) - 32 with two bins - whatever the number of bins per work-group
     ex.each(st, [&](int tid, FftState& s) {
 #pragma unroll
-        for (int q = 0; q < EMAX / S; ++q) {
-            const int r = tid + q * S * T;
-            if (r < R) {
-                cf2* dst = p.G + (size_t)r * p.pitchG + (size_t)bid * S;
-                if constexpr (S % 2 == 0) {
-                    // swap trick: true (re, im) = (xi, xr); two bins per 16-byte store (pitchG is
-                    // even and padded, so the pad columns absorb the tail of the last work-group)
+        for (int j = 0; j < EMAX / (2 * S); ++j) {
+            const int m = tid + j * S * T;
+            if (2 * m < R) {
+                cf4* dst = (cf4*)p.G + (size_t)m * p.pitchG + (size_t)bid * S;
+                const bool odd = 2 * m + 1 < R;
 #pragma unroll
-                    for (int g = 0; g < S; g += 2) {
-                        if (bid * S + g < p.pitchG) {
-                            cf4 v = {s.xi[q * S + g], s.xr[q * S + g], s.xi[q * S + g + 1], s.xr[q * S + g + 1]};
-                            *(cf4*)(dst + g) = v;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < S; ++g) {
-                        if (bid * S + g < p.pitchG) {
-                            cf2 v = {s.xi[q * S + g], s.xr[q * S + g]};
-                            dst[g] = v;
-                        }
+                for (int g = 0; g < S; ++g) {
+                    if (bid * S + g < p.pitchG) {
+                        // swap trick: true (re, im) = (xi, xr)
+                        const int e0 = (2 * j) * S + g, e1 = (2 * j + 1) * S + g;
+                        cf4 v = {s.xi[e0], s.xr[e0], odd ? s.xi[e1] : 0.f, odd ? s.xr[e1] : 0.f};
+                        dst[g] = v;
                     }
                 }
             }
@@ -800,8 +799,8 @@ SM_HD void k_i1_r1(Ex& ex, const I1Params& p) {
         for (int k2 = ex.bid() * nt + tid; k2 < p.Cb; k2 += ex.nblocks() * nt) {
             float re = p.reR[k2];
             if (fabsf(re) < thr) re = 0.f;
-            cf2 v = {re, p.imA[k2]};
-            p.G[k2] = v;
+            cf4 v = {re, p.imA[k2], 0.f, 0.f};           // row pair (0, -)
+            ((cf4*)p.G)[k2] = v;
         }
     });
 }
@@ -858,25 +857,22 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         const bool v0 = r0 < p.R, v1 = r1 < p.R;
         // loads are issued in two batches, none inside a divergent branch (out-of-range
         // ones are clamped to a valid address and masked), so each batch is in flight together
-        const cf2* G0 = p.G + (size_t)(v0 ? r0 : 0) * p.pitchG;
-        const cf2* G1 = p.G + (size_t)(v1 ? r1 : 0) * p.pitchG;
+        const cf4* GP = (const cf4*)p.G + (size_t)(v0 ? r0 / 2 : 0) * p.pitchG;     // row pairs, see k_i1
         constexpr int NU = EMAX / 2 + 1, HU = (NU + 1) / 2;
         static_for<0, 2>([&](auto half_c) {
             constexpr int u0 = decltype(half_c)::value * HU;
             constexpr int u1 = (u0 + HU < NU) ? u0 + HU : NU;
-            cf2 a0[HU], a1[HU];
+            cf4 ap[HU];
 #pragma unroll
             for (int u = u0; u < u1; ++u) {
                 const int k = t + u * T;
-                const int kc = k < p.Cb ? k : 0;
-                a0[u - u0] = G0[kc];
-                a1[u - u0] = G1[kc];
+                ap[u - u0] = GP[k < p.Cb ? k : 0];
             }
 #pragma unroll
             for (int u = u0; u < u1; ++u) {
                 const int k = t + u * T;
                 if (k < p.Cb) {
-                    cf2 g0 = a0[u - u0], g1 = a1[u - u0];
+                    cf2 g0 = {ap[u - u0].x, ap[u - u0].y}, g1 = {ap[u - u0].z, ap[u - u0].w};
                     if (!v0) { g0.x = 0.f; g0.y = 0.f; }
                     if (!v1) { g1.x = 0.f; g1.y = 0.f; }
                     if (k == 0 || 2 * k == C) { g0.y = 0.f; g1.y = 0.f; }   // c2r: DC / Nyquist are real

@@ -264,7 +264,7 @@ class Pipeline {
         g.R = R; g.C = C; g.full = full;
         g.Cb = full ? C : C / 2 + 1;
         g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
-        g.pitchG = 2 * g.pitch4;
+        g.pitchG = g.pitch4;           // G: row pairs x bins, float4 (two rows' float2) per entry
         g.ilv = t1_interleave(R);
         g.plane_floats = round_up((size_t)g.Cb * R, 64);
         g.Cw = full ? -1 : C;
@@ -344,7 +344,9 @@ class Pipeline {
 #else
     static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
     static int i1_bins_host(const FftPlanDev& pl) {
-        if (2 * pl.T > SM_COLS_MAX_THREADS) return 1;
+        // two bins per work-group up to 512 threads; the 512-thread plans run one bin per
+        // work-group (two independent groups per CU, as in the forward column pass)
+        if (2 * pl.T > SM_F2_MAX_THREADS) return 1;
         return is_static_plan(pl) ? i1_bins_for(pl.T) : 2;
     }
 #endif
