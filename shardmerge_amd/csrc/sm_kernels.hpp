@@ -200,7 +200,7 @@ struct F1Params {
     SigDesc a, b;
     int R, C, Cb;
     int pitch4;            // T1 row pitch in float4
-    int ilv;               // rows interleaved in T1 (1, 2 or 4): element (r, k) at ((r/ilv)*pitch4 + k)*ilv + r%ilv
+    int ilv;               // rows interleaved in T1 (1 or 2): element (r, k) at ((r/ilv)*pitch4 + k)*ilv + r%ilv
     int nb;                // rows (transforms) per work-group
     int vec;               // 1: C % 8 == 0 and 16-byte aligned inputs
     cf4* t1;               // the column pass reads ilv*16 contiguous bytes per (row group, bin)
@@ -505,8 +505,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                     s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
                 }
             };
-            if (ilv == 4) load_rows(std::integral_constant<int, 4>{});
-            else if (ilv == 2) load_rows(std::integral_constant<int, 2>{});
+            if (ilv == 2) load_rows(std::integral_constant<int, 2>{});
             else load_rows(std::integral_constant<int, 1>{});
         } else {
 #pragma unroll
@@ -538,8 +537,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                         if (n < R) { la[lpad(n)] = x[2 * q]; la[LF + lpad(n)] = x[2 * q + 1]; }
                     }
                 };
-                if (ilv == 4) scatter_rows(std::integral_constant<int, 4>{});
-                else if (ilv == 2) scatter_rows(std::integral_constant<int, 2>{});
+                if (ilv == 2) scatter_rows(std::integral_constant<int, 2>{});
                 else scatter_rows(std::integral_constant<int, 1>{});
             } else {
 #pragma unroll
@@ -666,13 +664,8 @@ constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 in
 #else
 constexpr int i1_bins_for(int T) { return (SM_I1_THREADS / T) > 2 ? ((SM_I1_THREADS / T) > 16 ? 16 : (SM_I1_THREADS / T)) : 2; }
 #endif
-#ifdef SM_NARROW_COLUMNS
-template <class P> constexpr int f2_bins() { return 1; }
-template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return P::T <= 512 ? 2 : 1; else return 2; }
-#else
 template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T); else return 1; }
 template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return i1_bins_for(P::T); else return 2; }
-#endif
 
 // =====================================================================
 // I1: inverse column pass

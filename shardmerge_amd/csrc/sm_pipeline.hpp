@@ -338,10 +338,6 @@ class Pipeline {
 #undef SM_IS_PLAN
         return found;
     }
-#ifdef SM_NARROW_COLUMNS
-    static int f2_bins_host(const FftPlanDev&) { return 1; }
-    static int i1_bins_host(const FftPlanDev& pl) { return 2 * pl.T <= 1024 ? 2 : 1; }
-#else
     static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
     static int i1_bins_host(const FftPlanDev& pl) {
         // two bins per work-group up to 512 threads; the 512-thread plans run one bin per
@@ -349,7 +345,6 @@ class Pipeline {
         if (2 * pl.T > SM_F2_MAX_THREADS) return 1;
         return is_static_plan(pl) ? i1_bins_for(pl.T) : 2;
     }
-#endif
 
     // launch the static-plan instantiation of a transform kernel when one matches
     template <template <class> class KT, class Params>
