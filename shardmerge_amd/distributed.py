@@ -137,6 +137,30 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     logger.info(f"rank {me}/{world}: {len(mine)} of {len(names)} tensors, "
                 f"{sum(c for c, o in zip(costs, owner) if o == me) / 1e9:.2f} GB algorithmic traffic")
 
+    # ---- this rank's finetune tensors are prefetched in processing order (loader.py); the base
+    # comes from the broadcast, passthrough tensors from whichever model provides them
+    my_order = [(s, name) for s in shards
+                for name in sorted((n for (ss, n) in mine if ss == s), key=layer_order.index)]
+    schedule = []
+    for (s, name) in my_order:
+        sl = ShardLayer(layer_order.index(name), s, name, False)
+        if sl.layer_number >= 0:
+            models = [m for m in config.finetune_merge if m.use_layer_index(sl.layer_number)]
+            uris = [m.model for m in models] + [m.base for m in models if m.base != base_uri]
+            schedule.append([(u, name) for u in dict.fromkeys(uris)])
+        else:
+            schedule.append(merger._layer_requests(sl))
+    loader = None
+    if os.environ.get("SHARDMERGE_PREFETCH", "1") != "0" and any(schedule):
+        from .loader import PrefetchLoader
+        loader = PrefetchLoader(index, str(dev))
+        loader.start(schedule)
+        merger._loader = loader
+    pos = {key: i for i, key in enumerate(my_order)}
+    import concurrent.futures
+    part_writer = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="shardmerge-part")
+    part_jobs = []
+
     # ---- per base shard: one broadcast, then every rank merges its own tensors -----------
     for si, s in enumerate(shards):
         root = si % world
@@ -162,6 +186,8 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             if shard_name != s:
                 continue
             sl = ShardLayer(layer_order.index(name), s, name, False)
+            if loader is not None:
+                loader.begin_layer(pos[(s, name)])
             if sl.layer_number >= 0:
                 out = await _merge_block_tensor(merger, engine, sl, views[name])
             else:
@@ -169,9 +195,16 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             merged[name] = out.detach().to("cpu").to(config.output_astype).contiguous()
         if merged:
             from safetensors.torch import save_file
-            save_file(merged, str(out_dir / f".part-{me}-{s}"), metadata={"format": "pt"})
+            # serialised in the background while the next shard is broadcast and merged
+            part_jobs.append(part_writer.submit(save_file, merged, str(out_dir / f".part-{me}-{s}"), {"format": "pt"}))
         del flat, views
 
+    for job in part_jobs:
+        job.result()
+    part_writer.shutdown()
+    if loader is not None:
+        loader.close()
+        merger._loader = None
     if world > 1:
         dist.barrier()
 
