@@ -105,6 +105,43 @@ def test_long_and_odd_lengths_on_device(engine, shape):
     assert d_resid < 2e-5 and d_total < 8.0 / math.sqrt(rows * cols)
 
 
+def test_random_shapes_and_noise_levels_vs_oracle(engine):
+    """A seeded sweep over random supported shapes (run-time planned lengths with factors up to
+    13, 1-D tensors, ragged sizes), noise levels and alphas against the exact-norm oracle
+    (tools/fuzz_gpu.py runs more of the same)."""
+    import random
+    rng = random.Random(7)
+    lens = [n for n in range(2, 2049) if all(_smooth(n))]
+    done = 0
+    while done < 14:
+        rows = rng.choice(lens + [1] * 200)
+        cols = rng.choice(lens)
+        if not (256 <= rows * cols <= 1 << 19):
+            continue
+        done += 1
+        g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+        shape = (cols,) if rows == 1 else (rows, cols)
+        base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+        sig = [10 ** rng.uniform(-3.2, -2.0) for _ in range(2)]
+        fts = [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16) for s_ in sig]
+        alphas = [rng.uniform(0.05, 1.0) for _ in range(2)]
+        trx = so.LayerTrace()
+        with so.exact_norms():
+            refx = so.merge_layer(fts, [base, base], alphas, base, trace=trx)
+        out, rep, delta = engine.merge_layer([t.cuda() for t in fts], [base.cuda()] * 2, alphas, base.cuda(), want_delta=True)
+        assert rep.branches == trx.branches, (rows, cols)
+        d_total, d_resid = pc.spectral_residual(delta.cpu().reshape(max(rows, 1), cols), trx.merged_delta.reshape(max(rows, 1), cols))
+        assert d_resid < 5e-5, (rows, cols, d_resid)
+        assert d_total < 10.0 / math.sqrt(rows * cols) + 1e-5, (rows, cols, d_total)
+
+
+def _smooth(n):
+    for p in (2, 3, 5, 7, 11, 13):
+        while n % p == 0:
+            n //= p
+    return [n == 1]
+
+
 def test_layer_k3_vs_oracle(engine):
     base, fts = so.synthetic_layer(1024, 1024, 3, seed=5000)
     tr = so.LayerTrace()
