@@ -118,3 +118,39 @@ def test_cli_output_is_the_same_with_and_without_prefetch(tmp_path, monkeypatch)
     assert outs[0].keys() == outs[1].keys()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_resume_recomputes_only_the_missing_shard(tmp_path, monkeypatch):
+    """A second run over a partly written output directory merges (and prefetches) only the
+    tensors of the shards that are missing (reference writer.py:93-113 resume semantics)."""
+    from tests.emul.loader import emul_engine
+    import shardmerge_amd.engine as eng_mod
+    import shardmerge_amd.loader as loader_mod
+    from shardmerge_amd.__main__ import cli
+    eng = emul_engine()
+    monkeypatch.setattr(eng_mod, "get_engine", lambda device=None: eng)
+    cfg_path = gi.write_cli_model(tmp_path)
+    res = CliRunner().invoke(cli, ["merge", str(cfg_path), "--cache-dir", str(tmp_path / "cache")])
+    assert res.exit_code == 0, res.output
+    out_dir = tmp_path / "merged"
+    shards = sorted(gi.CLI_SHARDS)
+    first = {}
+    for shard in shards:
+        with safe_open(str(out_dir / shard), framework="pt") as f:
+            first[shard] = {k: f.get_tensor(k) for k in f.keys()}
+    victim = shards[-1]
+    (out_dir / victim).unlink()
+    seen = []
+    real_start = loader_mod.PrefetchLoader.start
+
+    def spy(self, schedule):
+        seen.extend(name for reqs in schedule for (_, name) in reqs)
+        return real_start(self, schedule)
+
+    monkeypatch.setattr(loader_mod.PrefetchLoader, "start", spy)
+    res = CliRunner().invoke(cli, ["merge", str(cfg_path), "--cache-dir", str(tmp_path / "cache")])
+    assert res.exit_code == 0, res.output
+    assert seen and set(seen) <= {n for n, _ in gi.CLI_SHARDS[victim]}       # nothing of the finished shards is read again
+    with safe_open(str(out_dir / victim), framework="pt") as f:
+        for k in f.keys():
+            assert torch.equal(f.get_tensor(k), first[victim][k])
