@@ -1032,7 +1032,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
 // =====================================================================
 // streaming kernels over the half-spectrum planes [Cb][R]
 // =====================================================================
-struct EmptyState { double red[8]; };
+struct EmptyState { double red[8]; unsigned long long keep[8]; };
 
 SM_HD int sgn(float v) { return (v > 0.f) - (v < 0.f); }
 // torch.sign(NaN) = NaN and NaN == NaN is False: NaNs never "agree"
@@ -1411,29 +1411,46 @@ template <class Ex, class StT>
 SM_HD void wg_resolve(Ex& ex, StT& st, const unsigned long long* hist, int nbins, unsigned long long rank,
                       unsigned long long* part, uint32_t* res) {
     using S = typename StT::value_type;
-    const int nt = ex.nthreads();
-    const int per = (nbins + nt - 1) / nt;
-    ex.each(st, [&](int tid, S&) {
-        unsigned long long s = 0;
-        for (int b = tid * per; b < (tid + 1) * per && b < nbins; ++b) s += hist[b];
-        part[tid] = s;
+    const int nt = ex.nthreads();                       // 256
+    const int per = (nbins + nt - 1) / nt;              // <= 8: the thread's bins stay in its state
+    unsigned long long* grp = part + nt;                // 16 group totals (the scratch holds 2 * nt words)
+    ex.each(st, [&](int tid, S& s) {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int b = tid * per + q;
+            const unsigned long long h = (q < per && b < nbins) ? hist[b] : 0ull;
+            s.keep[q] = h;
+            sum += h;
+        }
+        part[tid] = sum;
         if (tid == 0) { res[0] = 0; res[1] = 0; res[2] = 0; }
     });
     ex.sync();
-    ex.each(st, [&](int tid, S&) {
+    ex.each(st, [&](int tid, S&) {                      // 16 threads total 16 partials each
+        if (tid < 16) {
+            unsigned long long g = 0;
+            for (int q = 0; q < 16; ++q) { const int i = tid * 16 + q; if (i < nt) g += part[i]; }
+            grp[tid] = g;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, S& s) {
         unsigned long long excl = 0, total = 0;
-        for (int q = 0; q < nt; ++q) { if (q < tid) excl += part[q]; total += part[q]; }
+        const int g0 = tid / 16;
+        for (int g = 0; g < 16; ++g) { const unsigned long long v = grp[g]; total += v; if (g < g0) excl += v; }
+        for (int q = g0 * 16; q < tid; ++q) excl += part[q];
         if (total == 0) return;
         unsigned long long r = rank >= total ? total - 1 : rank;
         if (r >= excl && r < excl + part[tid]) {
             unsigned long long cum = excl;
-            for (int b = tid * per; b < (tid + 1) * per && b < nbins; ++b) {
-                const unsigned long long h = hist[b];
-                if (r < cum + h) {
-                    res[0] = (uint32_t)b;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long h = s.keep[q];
+                if (q < per && r >= cum && r < cum + h) {
+                    res[0] = (uint32_t)(tid * per + q);
                     const unsigned long long nr = r - cum;
                     res[1] = (uint32_t)(nr & 0xffffffffull); res[2] = (uint32_t)(nr >> 32);
-                    break;
                 }
                 cum += h;
             }

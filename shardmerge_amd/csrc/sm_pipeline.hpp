@@ -480,7 +480,7 @@ class Pipeline {
 
         Select3Params t3;
         t3.cand = q.cand; t3.sel = d_sel(0); t3.hist2 = d_hist2(); t3.hist = d_hist3();
-        be.template launch<KSelect3>(CAND_GRID, 256, (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + 2 * 256) * 4, t3, stream);
+        be.template launch<KSelect3>(CAND_GRID, 256, (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + 2 * 256 + 32) * 4, t3, stream);
 
         s.hist = d_hist3(); s.sel = d_sel(1); s.nbins = HIST_LO_BINS; s.shift = 10; s.final_level = 1; s.init = 0;
         s.zero_also = d_hist(); s.zero_count = HIST1_BINS + HIST_LO_BINS;      // hist1 and hist2 (hist3 is s.hist)
