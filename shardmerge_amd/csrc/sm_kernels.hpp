@@ -1478,17 +1478,34 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
     unsigned long long* part = (unsigned long long*)(ex.lds() + LDS_SCRATCH_FLOATS);
-    const int nt = ex.nthreads();
-    const int per = (p.nbins + nt - 1) / nt;
-    ex.each(st, [&](int tid, EmptyState&) {
-        unsigned long long s = 0;
-        for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) s += p.hist[b];
-        part[tid] = s;
+    const int nt = ex.nthreads();                       // 256
+    const int per = (p.nbins + nt - 1) / nt;            // <= 8
+    unsigned long long* grp = part + nt;                // 16 group totals
+    ex.each(st, [&](int tid, EmptyState& s) {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int b = tid * per + q;
+            const unsigned long long h = (q < per && b < p.nbins) ? p.hist[b] : 0ull;
+            s.keep[q] = h;
+            sum += h;
+        }
+        part[tid] = sum;
     });
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
+        if (tid < 16) {
+            unsigned long long g = 0;
+            for (int q = 0; q < 16; ++q) { const int i = tid * 16 + q; if (i < nt) g += part[i]; }
+            grp[tid] = g;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState& s) {
         unsigned long long excl = 0, total = 0;
-        for (int q = 0; q < nt; ++q) { if (q < tid) excl += part[q]; total += part[q]; }
+        const int g0 = tid / 16;
+        for (int g = 0; g < 16; ++g) { const unsigned long long v = grp[g]; total += v; if (g < g0) excl += v; }
+        for (int q = g0 * 16; q < tid; ++q) excl += part[q];
         unsigned long long rank = p.init ? p.rank_init : p.sel->rank;
         const uint32_t prefix0 = p.init ? 0u : p.sel->prefix;
         const uint32_t level0 = p.init ? 0u : p.sel->level;
@@ -1496,10 +1513,11 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
         if (rank >= total) rank = total - 1;
         if (rank >= excl && rank < excl + part[tid]) {
             unsigned long long cum = excl;
-            for (int b = tid * per; b < (tid + 1) * per && b < p.nbins; ++b) {
-                const unsigned long long h = p.hist[b];
-                if (rank < cum + h) {
-                    const uint32_t np = (prefix0 << p.shift) | (uint32_t)b;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long h = s.keep[q];
+                if (q < per && rank >= cum && rank < cum + h) {
+                    const uint32_t np = (prefix0 << p.shift) | (uint32_t)(tid * per + q);
                     p.sel->prefix = np;
                     p.sel->rank = rank - cum;
                     p.sel->level = level0 + 1;
@@ -1507,7 +1525,6 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
                         p.sel->value = u2f(np);
                         if (p.value_out) *p.value_out = u2f(np);
                     }
-                    break;
                 }
                 cum += h;
             }

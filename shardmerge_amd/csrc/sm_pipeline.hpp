@@ -449,7 +449,7 @@ class Pipeline {
         h.hist = d_hist(); h.chunks = pick_chunks((total + 3) / 4, 256, 8); h.only_if = nullptr;
         const int hgrid = stream_grid((total + 3) / 4, 256, h.chunks);
         const size_t hlds = (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4;
-        const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256) * 4;
+        const size_t scan_lds = (LDS_SCRATCH_FLOATS + 2 * 256 + 32) * 4;
         ScanParams s;
         s.hist = d_hist(); s.sel = d_sel(0); s.value_out = thr_out; s.zero_also = nullptr; s.zero_count = 0;
         s.zero_u32 = nullptr; s.zero_u32_count = 0;
