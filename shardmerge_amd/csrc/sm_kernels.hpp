@@ -1737,29 +1737,59 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
     }
     ex.each(st, [&](int tid, EmptyState&) {
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
-        for (int q = 0; q < p.chunks; ++q) {
-            const size_t qi = start + (size_t)q * nt + tid;
-            if (qi >= nquad) break;
-            const size_t i0 = 4 * qi;
-            float a[4], b[4], r[4];
-            const int n = load_quad(p.reA, i0, total, p.vec4, a);
-            load_quad(p.reB, i0, total, p.vec4, b);
+        auto quad = [&](size_t i0, const float* a, const float* b, int n, bool vec) {
+            float r[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) r[e] = blend_one(p, c, a[e], b[e]);
-            if (p.vec4) {
+            if (vec) {
                 cf4 v = {r[0], r[1], r[2], r[3]};
                 *(cf4*)(p.reR + i0) = v;
             } else {
                 for (int e = 0; e < n; ++e) p.reR[i0 + e] = r[e];
             }
             if (p.hist) {
+                const uint32_t w0 = weight_at(wr, i0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (e < n) {
                         const uint32_t key = f2u(r[e]) & 0x7fffffffu;
-                        ex.lds_atomic_add(&lh[key >> 20], weight_at(wr, i0 + e));
+                        ex.lds_atomic_add(&lh[key >> 20], (vec && !wr.full) ? w0 : weight_at(wr, i0 + e));
                     }
                 }
+            }
+        };
+        if (p.vec4) {
+            // 16-byte loads of U steps in flight together (clamped, not branched around)
+            constexpr int U = 4;
+            const cf4* A4 = (const cf4*)p.reA;
+            const cf4* B4 = (const cf4*)p.reB;
+            for (int q0 = 0; q0 < p.chunks; q0 += U) {
+                cf4 av[U], bv[U];
+                size_t qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    qv[u] = start + (size_t)(q0 + u) * nt + tid;
+                    av[u] = A4[qv[u] < nquad ? qv[u] : nquad - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) bv[u] = B4[qv[u] < nquad ? qv[u] : nquad - 1];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (q0 + u < p.chunks && qv[u] < nquad) {
+                        const float a[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+                        const float b[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+                        quad(4 * qv[u], a, b, 4, true);
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < p.chunks; ++q) {
+                const size_t qi = start + (size_t)q * nt + tid;
+                if (qi >= nquad) break;
+                float a[4], b[4];
+                const int n = load_quad(p.reA, 4 * qi, total, 0, a);
+                load_quad(p.reB, 4 * qi, total, 0, b);
+                quad(4 * qi, a, b, n, false);
             }
         }
     });
