@@ -3,6 +3,7 @@
 // profiling) and the C ABI of include/shardmerge_hip.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC (see Makefile).
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -80,11 +81,12 @@ struct HipBackend {
     template <class K>
     void launch(int grid, int block, size_t lds_bytes, const typename K::Params& p, void* s) {
         if (!ok()) return;
-        static size_t lds_set = 0;                 // per kernel instantiation
-        if (lds_bytes > lds_set) {
+        static std::atomic<size_t> lds_set{0};     // per kernel instantiation; contexts of several threads share it
+        if (lds_bytes > lds_set.load(std::memory_order_relaxed)) {
             check(hipFuncSetAttribute((const void*)sm_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
                   "hipFuncSetAttribute");
-            lds_set = lds_bytes;
+            size_t seen = lds_set.load(std::memory_order_relaxed);
+            while (seen < lds_bytes && !lds_set.compare_exchange_weak(seen, lds_bytes, std::memory_order_relaxed)) {}
         }
         hipStream_t st = (hipStream_t)s;
         if (profiling) check(hipEventRecord(ev0, st), "hipEventRecord");
