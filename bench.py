@@ -54,7 +54,9 @@ def workload_shapes(name: str, blocks: int):
 
 def alg_bytes_per_elem(k: int) -> int:
     """B_alg = 60n (K=2), 122n (K=3), 182n (K=4)."""
-    return {1: 8, 2: 60, 3: 122, 4: 182}.get(k, 60 * (k - 1) + 2 * (k - 2))
+    if k <= 1:
+        return 8
+    return 60 * (k // 2) + 62 * (k - 1 - k // 2)       # floor(k/2) raw pairs, the other pairs see an fp32 intermediate
 
 
 # algorithmic HBM bytes of ONE launch of each kernel on a tensor of n elements

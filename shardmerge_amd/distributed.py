@@ -47,11 +47,13 @@ def local_rank() -> int:
 
 
 def alg_bytes(numel: int, k: int) -> int:
-    """Algorithmic HBM bytes of merging one tensor with k finetunes:
-    60n for one raw pair, +62n for every further pair merge, 8n for k = 1."""
+    """Algorithmic HBM bytes of merging one tensor with k finetunes: k - 1 pair
+    merges, 60n for the floor(k/2) pairs of raw deltas of the first round, 62n for every pair
+    with an fp32 intermediate; 8n for k = 1."""
     if k <= 1:
         return 8 * numel
-    return numel * (60 + 62 * (k - 2))
+    raw_pairs = k // 2
+    return numel * (60 * raw_pairs + 62 * (k - 1 - raw_pairs))
 
 
 def partition_lpt(costs: List[int], world: int) -> List[int]:
