@@ -207,6 +207,10 @@ struct F1Params {
     double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
 };
 
+template <class P> constexpr bool f1_full_batch() {
+    if constexpr (P::is_static) return P::T <= 256; else return false;
+}
+
 template <class P, class Ex>
 SM_HD void k_f1(Ex& ex, const F1Params& p) {
     typename Ex::template State<FftState> st;
@@ -248,19 +252,27 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
             const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
             const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
+            // the 128-VGPR variants (512/1024-thread work-groups, run-time plans) keep half of the
+            // row's loads in flight at a time: all sixteen at once made them spill
+            constexpr int QB = f1_full_batch<P>() ? NQ : NQ / 2;
+            bool all_ok = true;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) ra[q] = pa[off[q]];
+            for (int q = 0; q < NQ; ++q) all_ok = all_ok && ok[q];
+            static_for<0, NQ / QB>([&](auto h_c) {
+            constexpr int Q0 = decltype(h_c)::value * QB, Q1 = Q0 + QB;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rab[q] = pab[off[q]];
+            for (int q = Q0; q < Q1; ++q) ra[q] = pa[off[q]];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rb[q] = pb[off[q]];
+            for (int q = Q0; q < Q1; ++q) rab[q] = pab[off[q]];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rbb[q] = pbb[off[q]];
+            for (int q = Q0; q < Q1; ++q) rb[q] = pb[off[q]];
+#pragma unroll
+            for (int q = Q0; q < Q1; ++q) rbb[q] = pbb[off[q]];
             // MASKED: some loads of this thread were clamped (ragged row tail, padded grid)
             auto decode = [&](auto masked_c) {
                 constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
+                for (int q = Q0; q < Q1; ++q) {
                     float va[8], vb[8], ba[8], bb[8];
                     decode16x8(ra[q], p.a.dtype, va);
                     decode16x8(rab[q], p.a.dtype, ba);
@@ -284,11 +296,10 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
                     sa += pa; sb += pb;
                 }
             };
-            bool all_ok = true;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) all_ok = all_ok && ok[q];
             if (all_ok) decode(std::false_type{});
             else decode(std::true_type{});
+            });
+
         } else if (vec) {
             // any other dtype mix (later tournament rounds: an fp32 intermediate against a raw
             // bf16 delta): one signal at a time, its loads issued together, decoded afterwards
