@@ -210,6 +210,11 @@ struct F1Params {
 template <class P> constexpr bool f1_full_batch() {
     if constexpr (P::is_static) return P::T <= 256; else return false;
 }
+// paired (packed-f32) butterflies cost registers: the 512/1024-thread row plans, compiled for
+// 128 VGPRs, spill with them (14336: 76 bytes of scratch -> 0, -21 % time) and stay scalar
+template <class P> constexpr bool f1_pack() {
+    if constexpr (P::is_static) return P::T <= 256; else return true;
+}
 
 template <class P, class Ex>
 SM_HD void k_f1(Ex& ex, const F1Params& p) {
@@ -383,7 +388,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         p.partials[2 * (size_t)pbid + 1] = tot[1];
     });
 
-    wg_fft<P>(ex, st, pl, lds,
+    wg_fft<P, f1_pack<P>()>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;          // natural scatter
             const int g = tid / T, t = tid % T;
@@ -891,7 +896,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         });
     });
 
-    wg_fft<P>(ex, st, pl, lds,
+    wg_fft<P, f1_pack<P>()>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
