@@ -212,8 +212,11 @@ template <class P> constexpr bool f1_full_batch() {
 }
 // paired (packed-f32) butterflies cost registers: the 512/1024-thread row plans, compiled for
 // 128 VGPRs, spill with them (14336: 76 bytes of scratch -> 0, -21 % time) and stay scalar
+#ifndef SM_ROW_PACK_MAX_T
+#define SM_ROW_PACK_MAX_T 256
+#endif
 template <class P> constexpr bool f1_pack() {
-    if constexpr (P::is_static) return P::T <= 256; else return true;
+    if constexpr (P::is_static) return P::T <= SM_ROW_PACK_MAX_T; else return true;
 }
 
 template <class P, class Ex>
