@@ -47,7 +47,10 @@ SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)), 1, 4)
 SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)), i1_bins<P>(), 4)
 SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
 
-// lengths that get straight-line kernels; must agree with plan_shape() below
+// lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
+// and the 3/5/7 * 2^k hidden and MLP sizes of other common models: a run-time planned length
+// runs the same code with its register arrays in scratch memory, 5120^2: 5.4 ms against 0.7);
+// must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
 // largest work-group the column passes may use (A and B / two bins together)
 #ifndef SM_COLS_MAX_THREADS
@@ -73,7 +76,14 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
     X(SPlan<8192, SM_T8192, false, SM_W8192, SM_R8192>)  \
     X(SPlan<16384, 512, false, 4, 32, 32, 16>)\
     X(SPlan<14336, 512, false, 4, SM_R14336>) \
-    X(SPlan<28672, 1024, false, 4, 16, 16, 16, 7>)
+    X(SPlan<28672, 1024, false, 4, 16, 16, 16, 7>) \
+    X(SPlan<3072, 128, false, 4, 16, 16, 4, 3>)    \
+    X(SPlan<3584, 128, false, 4, 16, 32, 7>)       \
+    X(SPlan<5120, 256, false, 4, 16, 16, 4, 5>)    \
+    X(SPlan<6144, 256, false, 4, 16, 16, 8, 3>)    \
+    X(SPlan<7168, 256, false, 4, 16, 16, 4, 7>)    \
+    X(SPlan<12288, 512, false, 4, 16, 16, 16, 3>)  \
+    X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
 // 1.6x slower than split exchanges, so no plan uses it for now
