@@ -83,7 +83,9 @@ SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
     X(SPlan<6144, 256, false, 4, 16, 16, 8, 3>)    \
     X(SPlan<7168, 256, false, 4, 16, 16, 4, 7>)    \
     X(SPlan<12288, 512, false, 4, 16, 16, 16, 3>)  \
-    X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>)
+    X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>) \
+    X(SPlan<27648, 1024, false, 4, 32, 32, 3, 3, 3>) \
+    X(SPlan<2304, 128, false, 4, 16, 16, 3, 3>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
 // 1.6x slower than split exchanges, so no plan uses it for now

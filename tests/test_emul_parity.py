@@ -137,7 +137,7 @@ def test_heavy_ties(engine):
     assert resid < 1e-4
 
 
-@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 14336, 28672, 7168, 3072, 5120, 6144, 3584, 12288, 13824, 1536, 2560])
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192, 16384, 14336, 28672, 7168, 3072, 5120, 6144, 3584, 12288, 13824, 27648, 2304, 1536, 2560])
 def test_static_and_dynamic_plan_lengths(engine, n):
     """Every straight-line (static plan) length and a few run-time planned ones, as a
     row transform (2 x n) and as a column transform (n x 2)."""

@@ -85,7 +85,7 @@ def test_layer_k2_vs_oracle(engine, shape):
 
 
 @pytest.mark.parametrize("shape", [(28672, 16), (16, 28672), (14336, 32), (8, 4096), (16384, 8), (3072, 40),
-                                   (5120, 24), (24, 5120), (6144, 16), (16, 7168), (12288, 8), (16, 3584), (2560, 48), (13824, 8), (8, 13824)],
+                                   (5120, 24), (24, 5120), (6144, 16), (16, 7168), (12288, 8), (16, 3584), (2560, 48), (13824, 8), (8, 13824), (27648, 8), (8, 27648), (2304, 32)],
                          ids=lambda s: f"{s[0]}x{s[1]}")
 def test_long_and_odd_lengths_on_device(engine, shape):
     """Llama-3-70B / Mixtral lengths (7 * 2^12, 7 * 2^11, the 8 x 4096 router) and run-time
