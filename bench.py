@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py - merged-weight GB/s of the spectral-merge hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3-8b|8192sq|llama3-70b-slice] [--k K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload llama3-70b-slice|llama3-8b|8192sq] [--k K]
+
+Default workload = the configuration BASELINE.json's metric is quoted on: the Llama-3-70B
+3-finetune merge, this GPU's 1/8 slice of the block tensors (10 of 80 blocks), K = 3.
+`--gpus N` without a torchrun environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned before this process touches the GPU).
 
 One "step" = one pass of the hot path (shardmerge_amd Engine.merge_layer through
 libshardmerge_hip.so: deltas -> forward 2-D FFT -> order statistics -> SLERP blend
@@ -52,6 +57,21 @@ def workload_shapes(name: str, blocks: int):
     raise SystemExit(f"unknown workload {name}")
 
 
+def self_launch(n_gpus: int, argv):
+    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD process (this process has not
+    initialised the GPU yet and never does) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def alg_bytes_per_elem(k: int) -> int:
     """B_alg = 60n (K=2), 122n (K=3), 182n (K=4)."""
     if k <= 1:
@@ -59,20 +79,34 @@ def alg_bytes_per_elem(k: int) -> int:
     return 60 * (k // 2) + 62 * (k - 1 - k // 2)       # floor(k/2) raw pairs, the other pairs see an fp32 intermediate
 
 
-# algorithmic HBM bytes of ONE launch of each kernel on a tensor of n elements
-# (SURVEY 8(d) phase table: P1 = F1, P2 = F2, P3/P6 = select_hist, P4 = reduce,
-#  P5 = blend, P7 = I1, P8 = I2)
+# algorithmic HBM bytes per element of ONE launch of each kernel on a RAW pair (both inputs
+# bf16 deltas sharing a base) - SURVEY 8(d) phase table: P1 = F1, P2 = F2, P3/P6 = selection,
+# P4 = reduce (fused away), P5 = blend, P7 = I1, P8 = I2
 KERNEL_ALG_BYTES = {
     "f1_rows_fwd": 14.0,     # read 3 bf16 tensors (6n) + write two half-spectra (8n)
     "f2_cols_fwd": 14.0,     # read 8n + write Re a, Im a, Re b (6n)
     "i1_cols_inv": 8.0,      # read Re R + Im a (4n) + write 4n
-    "i2_rows_inv": 8.0,      # read 4n + base 2n + write bf16 2n
+    "i2_rows_inv": 8.0,      # read 4n + base 2n + write bf16 2n   (or: read 4n + write fp32 4n)
     "blend": 6.0,
     "slerp_reduce": 4.0,
     "select_lvl2": 3.0,      # 4n on (Re a, Re b) + 2n on Re R: two launches per pair, 3n on average
     "select_hist": 3.0,
     "combine": 6.0,
 }
+
+
+def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
+    """Algorithmic bytes per tensor element summed over ALL launches of kernel `name` in one
+    K-way layer merge (K-1 pair merges; from the second round on one input of a pair is an
+    fp32 intermediate: its F1 reads 4n + 4n instead of 6n)."""
+    pairs = max(k - 1, 1)
+    raw = k // 2                                 # pairs whose two inputs are raw bf16 deltas
+    per = KERNEL_ALG_BYTES.get(name, 0.0)
+    if name == "f1_rows_fwd":
+        return raw * 14.0 + (pairs - raw) * 16.0
+    if name in ("select_lvl2", "select_hist"):
+        return per * 2 * pairs                   # two launches per pair
+    return per * pairs
 
 
 def make_inputs(shapes, k, device, seed, shared_base=None):
@@ -137,28 +171,57 @@ def run_step(engines, layers, k):
     return sum(counts)
 
 
+CPU_BASELINE_THREADS = 16      # capped: the sort-bound oracle gets SLOWER with hundreds of threads
+
+
 def cpu_baseline(k: int):
-    """The CPU oracle on a bounded sample of the same workload (one 4096 x 4096
-    block tensor, K as benchmarked): about 10-30 s of host work."""
+    """The CPU oracle on a bounded sample of the workload: ONE pair merge (K = 2) of one
+    synthetic [8192 x 8192] bf16 tensor - SURVEY 8(d)'s micro-benchmark shape, 30-40 s of host
+    work on a stated, capped number of threads.  A K-way layer is K-1 such pair merges, so the
+    rate that corresponds to the benchmarked K is value / (K-1) (reported as value_for_k)."""
     from oracle import spectral_oracle as so
-    rows = cols = 4096
-    base, fts = so.synthetic_layer(rows, cols, k, seed=1000)
-    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    rows = cols = 8192
+    base, fts = so.synthetic_layer(rows, cols, 2, seed=1000)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(CPU_BASELINE_THREADS, avail))
+    torch.set_num_threads(threads)
     t0 = time.time()
-    so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base)
+    so.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base)
     dt = time.time() - t0
-    return {"value": 2.0 * rows * cols / dt / 1e9, "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle.merge_layer on one synthetic [{rows}x{cols}] bf16 tensor, K={k} ({dt:.1f} s)"}
+    v = 2.0 * rows * cols / dt / 1e9
+    return {"value": v, "unit": "GB/s", "cores": threads, "kind": "port",
+            "value_for_k": v / max(k - 1, 1),
+            "sample": f"oracle.merge_layer (one SLERP-FFT pair merge, K=2) on one synthetic [{rows}x{cols}] bf16 tensor, "
+                      f"{threads} threads of {avail} available ({dt:.1f} s); a K={k} layer is {max(k - 1, 1)} pair merges"}
+
+
+def load_traffic(workload: str, k: int, kernel: str):
+    """Per-launch HBM bytes of `kernel` from the committed rocprofv3 --pmc summary
+    (profiles/traffic_latest.json, written by tools/traffic_run.sh).  The file is stamped with
+    the workload it was measured on; a stamp that does not match this run gives None (traffic
+    is per-launch on a shape mix: another workload's number would be wrong, not stale)."""
+    tf = REPO / "profiles" / "traffic_latest.json"
+    if not tf.exists():
+        return None
+    try:
+        data = json.load(open(tf))
+    except Exception:
+        return None
+    meta = data.get("_meta", {})
+    if meta.get("workload") != workload or int(meta.get("k", -1)) != int(k):
+        return None
+    return data.get(kernel, {}).get("hbm_bytes_per_launch")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="llama3-8b")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="llama3-70b-slice",
+                    help="llama3-70b-slice (default: the metric's configuration) | llama3-8b | 8192sq")
     ap.add_argument("--blocks", type=int, default=0)
-    ap.add_argument("--k", type=int, default=2)
+    ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--streams", type=int, default=8, help="tensors merged concurrently (one engine/stream/workspace each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -167,9 +230,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: start the ranks as a child before anything here touches the GPU
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU.  (Rehearsal on a one-GPU box: SHARDMERGE_BENCH_BACKEND=gloo lets several
     # ranks share the card - RCCL itself refuses two ranks on one device.)
     backend = os.environ.get("SHARDMERGE_BENCH_BACKEND", "nccl")
@@ -239,7 +304,7 @@ def main():
         "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{desc}, K={k} finetunes, bf16 in/out, resident in HBM", "tensors_per_step": len(shapes),
+        "config": {"workload": f"{desc}, K={k} finetunes, bf16 in/out, resident in HBM", "workload_id": args.workload, "tensors_per_step": len(shapes),
                    "params_per_step_per_gpu": n_elems, "k": k, "parallelism": f"tensor-partition x{world} (no data-path collective)", "streams_per_gpu": len(engines)},
         "per_gpu_GBps": value / world,
         "pipeline_hbm_frac": alg_bytes_per_elem(k) * n_elems * args.steps / dt / HBM_PEAK,
@@ -259,25 +324,21 @@ def main():
         kern = {name: {"launches": n, "total_ms": round(ms, 3), "share": round(ms / tot_ms, 4) if tot_ms else 0}
                 for name, (n, ms) in table.items()}
         dom = max(table.items(), key=lambda kv: kv[1][1])[0]
-        # algorithmic bytes of the dominant kernel over the step: per-element bytes of one
-        # launch (SURVEY 8d / DESIGN.md 5) x elements of every tensor it ran on (K-1 pair
-        # merges per tensor; the selection pass runs once on 2 planes and once on 1: 4n + 2n)
-        pairs = max(k - 1, 1)
+        # algorithmic bytes of the dominant kernel over the step: per-element bytes of its
+        # launches on one tensor (SURVEY 8d / DESIGN.md 5) x elements of every tensor
         n_2d = sum(r * c for r, c in shapes)
-        per_elem = KERNEL_ALG_BYTES.get(dom, 0.0)
-        alg = per_elem * n_2d * pairs * (2 if dom == "select_lvl2" else 1)
+        per_elem = kernel_alg_bytes_per_elem(dom, k)
+        alg = per_elem * n_2d
         launches, dom_ms = table[dom]
-        traffic = None
-        tf = REPO / "profiles" / "traffic_latest.json"
-        if tf.exists():
-            try:
-                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = load_traffic(args.workload, k, dom)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": alg / (dom_ms / 1e3) / HBM_PEAK, "traffic": traffic,
                               "alg_bytes_per_launch": alg / launches, "avg_launch_ms": dom_ms / launches,
-                              "alg_bytes_per_elem": per_elem}
+                              "alg_bytes_per_elem_per_layer": per_elem}
+        # every streaming kernel's own fraction of the HBM peak (same measurement)
+        result["kernel_hbm_frac"] = {
+            name: round(kernel_alg_bytes_per_elem(name, k) * n_2d / (ms / 1e3) / HBM_PEAK, 4)
+            for name, (n, ms) in table.items() if kernel_alg_bytes_per_elem(name, k) > 0 and ms > 0}
         result["kernels"] = kern
         result["device_ms_profiled_step"] = round(tot_ms, 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

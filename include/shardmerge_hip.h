@@ -33,7 +33,9 @@ enum {
     SMHIP_ERR_INF_IFFT = 3,    /* "Inf in ifft output"            (functions.py:215-217) */
     SMHIP_ERR_INF_MERGED = 4,  /* "Inf in merged tensor for ..."  (fast_fourier.py:273-274) */
     SMHIP_ERR_ARG = 5,
-    SMHIP_ERR_NOMEM = 6
+    SMHIP_ERR_NOMEM = 6,
+    SMHIP_ERR_NONFINITE = 7    /* a delta norm is NaN/Inf (K >= 2): the reference's tournament loop
+                                  (fast_fourier.py:171-254) never terminates on such input */
 };
 
 enum { SMHIP_BF16 = 0, SMHIP_F16 = 1, SMHIP_F32 = 2 };

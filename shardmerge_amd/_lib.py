@@ -16,7 +16,7 @@ from typing import Optional
 MAX_MODELS = 16
 MAX_PAIRS = 32
 
-OK, ERR_HIP, ERR_SHAPE, ERR_INF_IFFT, ERR_INF_MERGED, ERR_ARG, ERR_NOMEM = range(7)
+OK, ERR_HIP, ERR_SHAPE, ERR_INF_IFFT, ERR_INF_MERGED, ERR_ARG, ERR_NOMEM, ERR_NONFINITE = range(8)
 BF16, F16, F32 = 0, 1, 2
 BRANCH_NAMES = {0: "add", 1: "arith", 2: "slerp", 3: "carry", 4: "early_v0", 5: "linear"}
 

@@ -932,6 +932,17 @@ class Pipeline {
             norms32[i] = (float)stack[i].norm;           // torch.norm of an fp32 tensor is fp32
             rp.delta_norm[i] = norms32[i];
         }
+        // A NaN/Inf norm (NaN or Inf element in a finetune or base) makes the pairing find no
+        // pair, every slot is carried and the loop below would never end - the reference does
+        // spin there.  Deviation: a loud error.
+        for (int i = 0; i < d.k; ++i) {
+            if (!std::isfinite(norms32[i])) {
+                char buf[96];
+                snprintf(buf, sizeof buf, "||finetune[%d] - base[%d]|| = %g", i, i, (double)norms32[i]);
+                check_flags(false, false);
+                return fail(SMHIP_ERR_NONFINITE, buf);
+            }
+        }
         {   // torch.tensor(layer_norms).mean(): fp32 mean
             float acc = 0.f;
             for (int i = 0; i < d.k; ++i) acc += norms32[i];
@@ -951,6 +962,9 @@ class Pipeline {
             correlated_pairs_least(norms32, m, pairs);   // Q1: first m entries of the ORIGINAL norm list
             std::vector<Slot> next;
             const bool last_round = (pairs.size() == 1 && pairs[0].second >= 0);
+            bool any_pair = false;
+            for (auto& pr : pairs) any_pair = any_pair || pr.second >= 0;
+            if (!any_pair) { check_flags(false, false); return fail(SMHIP_ERR_NONFINITE, "no pair can be formed (non-finite norms)"); }
             for (auto& pr : pairs) {
                 const int x = pr.first, y = pr.second;
                 if (step < SMHIP_MAX_PAIRS) { rp.step_x[step] = x; rp.step_y[step] = y; }

@@ -116,6 +116,13 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     shards = sorted(set(weight_map.values()))
     out_dir = config.output_path
     out_dir.mkdir(parents=True, exist_ok=True)
+    # part files of an earlier (crashed) run - another partition, world size or configuration -
+    # must never be assembled into this run's shards
+    if me == 0:
+        for stale in list(out_dir.glob(".part-*")) + list(out_dir.glob(".tmp-*")):
+            stale.unlink()
+    if world > 1:
+        dist.barrier()
 
     # ---- plan: the same on every rank --------------------------------------------------
     metas = {s: _tensor_meta(index, base_uri, s) for s in shards}
@@ -217,17 +224,22 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
         if si % world != me:
             continue
         tensors = {}
+        planned = {names[i][1]: owner[i] for i in range(len(names)) if names[i][0] == s}
         for r in range(world):
             part = out_dir / f".part-{r}-{s}"
             if part.exists():
                 with safe_open(str(part), framework="pt") as fh:
                     for k in fh.keys():
+                        if planned.get(k) != r:
+                            raise RuntimeError(f"{part.name} holds {k}, which the plan gave to rank {planned.get(k)}")
                         tensors[k] = fh.get_tensor(k)
         expected = {n for n in weight_map if weight_map[n] == s}
         if set(tensors) != expected:
             raise RuntimeError(f"Incomplete model output: shard {s} is missing {sorted(expected - set(tensors))}")
         ordered = {k: tensors[k] for k in sorted(tensors, key=layer_order.index)}
-        save_file(ordered, str(out_dir / s), metadata={"format": "pt"})
+        tmp = out_dir / f".tmp-{me}-{s}"
+        save_file(ordered, str(tmp), metadata={"format": "pt"})
+        os.replace(tmp, out_dir / s)                     # a shard file is either absent or complete
     if world > 1:
         dist.barrier()
     if me == 0:

@@ -30,6 +30,10 @@ def _raise_like_reference(e: SmhipError, layer_name: Optional[str] = None):
         raise ValueError(f"Inf in merged tensor for {layer_name}") from e  # fast_fourier.py:274
     if e.code == _lib.ERR_SHAPE:
         raise NotImplementedError(e.message) from e
+    if e.code == _lib.ERR_NONFINITE:
+        # the reference spins forever here (no pair is ever found among NaN norms,
+        # fast_fourier.py:171-254); a loud error instead - INTEGRATION.md "deviations"
+        raise ValueError(f"Non-finite delta norm in {layer_name}: {e.message}") from e
     raise e
 
 
@@ -177,7 +181,11 @@ class Engine:
         k = len(finetunes)
         if k < 1 or k > _lib.MAX_MODELS:
             raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
-        in_dtype = finetunes[0].dtype
+        # one input dtype per call (smhip_layer_desc.in_dtype).  Mixed dtypes are PROMOTED to
+        # fp32, never demoted: the reference upcasts every tensor to fp32 before subtracting
+        # (base.py:128-131), so an fp32 base next to bf16 finetunes must keep its low bits
+        dtypes = {t.dtype for t in list(finetunes) + list(bases)}
+        in_dtype = next(iter(dtypes)) if len(dtypes) == 1 else torch.float32
         if in_dtype not in _DTYPE_CODE:
             in_dtype = torch.float32
         keep = []           # keep device copies alive until the call returns

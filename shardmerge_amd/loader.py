@@ -170,6 +170,11 @@ class PrefetchLoader:
         if ev is not None:
             ev.synchronize()                  # copy done: the pinned buffer may go
             del host
+            # `dev` was allocated on the copy stream's pool but is consumed (merge kernels, the
+            # writer's asynchronous device-to-host copy of passthrough tensors) on the caller's
+            # stream: without this the block returns to the copy stream's pool the moment the
+            # caller drops it and the next prefetch may overwrite it under a copy still in flight
+            dev.record_stream(torch.cuda.current_stream(self.device))
         return dev
 
     def close(self):

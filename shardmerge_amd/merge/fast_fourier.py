@@ -52,6 +52,41 @@ class FourierMerge(MergeTensorsBase):
             self._engine = get_engine(device)
         return self._engine
 
+    async def initialize(self):
+        """reference base.py:139-162, plus a shape pre-flight: every block tensor's transform
+        lengths are checked against the HIP library BEFORE any layer is merged (an unsupported
+        length used to surface only when its first layer came up, after earlier shards had been
+        written - and, under torchrun, with the other ranks parked in a collective)."""
+        await super().initialize()
+        self.check_transform_lengths()
+
+    def check_transform_lengths(self):
+        import json
+        lib = self._engine.lib if self._engine is not None else None
+        if lib is None:
+            from .. import _lib
+            lib = _lib.get_lib()
+        uri = self.config.output_base_model
+        weight_map = self.index_manager.model_indexes[uri]["weight_map"]
+        bad, seen = [], {}
+        for shard in sorted(set(weight_map.values())):
+            path = self.index_manager.storage_path / uri / shard
+            with open(path, "rb") as fh:
+                n = int.from_bytes(fh.read(8), "little")
+                header = json.loads(fh.read(n))
+            for name, rec in header.items():
+                if not name.startswith("model.layers."):
+                    continue
+                for length in rec["shape"][-2:]:
+                    if length not in seen:
+                        seen[length] = lib.length_supported(int(length))
+                    if not seen[length]:
+                        bad.append(f"{name} {rec['shape']} (length {length})")
+        if bad:
+            raise NotImplementedError(
+                f"{len(bad)} block tensor(s) have a transform length the HIP library does not support, "
+                f"e.g. {bad[0]}; nothing was merged")
+
     def get_readme(self) -> str:
         models = "\n".join(f"- {m.model} (vs {m.base})" for m in self.config.finetune_merge)
         return f"# SLERP-FFT Merged Model\nBase: {self.config.output_base_model}\nModels merged:\n{models}\n"

@@ -13,6 +13,7 @@ and the file is written once when the shard is complete (or at ``finalize`` /
 from __future__ import annotations
 
 import json
+import os
 import queue
 import threading
 import logging
@@ -140,7 +141,9 @@ class ModelWriter:
                 ev.synchronize()
             merged[k] = t
         ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
-        save_file(ordered, str(path), metadata={"format": "pt"})
+        tmp = path.with_name(f".tmp-{path.name}")
+        save_file(ordered, str(tmp), metadata={"format": "pt"})
+        os.replace(tmp, path)                  # resume must never see a half-written shard
         with self._lock:
             for k in fresh:
                 self.written_shard_layers.add((name, k))

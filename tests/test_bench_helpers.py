@@ -35,6 +35,57 @@ def test_algorithmic_bytes_model(bench):
     # the per-kernel table adds up to the pipeline total of one raw pair minus the reduction pass that is fused away
     t = bench.KERNEL_ALG_BYTES
     assert t["f1_rows_fwd"] + t["f2_cols_fwd"] + 2 * t["select_lvl2"] + t["blend"] + t["i1_cols_inv"] + t["i2_rows_inv"] == 56
+    # per layer: K-1 pair merges, an fp32 intermediate costs the row pass 2n more
+    names = ["f1_rows_fwd", "f2_cols_fwd", "select_lvl2", "blend", "i1_cols_inv", "i2_rows_inv"]
+    assert sum(bench.kernel_alg_bytes_per_elem(n, 2) for n in names) == 56
+    assert sum(bench.kernel_alg_bytes_per_elem(n, 3) for n in names) == 56 + 58
+    assert bench.kernel_alg_bytes_per_elem("publish", 3) == 0
+
+
+def test_default_workload_is_the_metrics_configuration(bench, monkeypatch):
+    import sys
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    import argparse
+    seen = {}
+    real = argparse.ArgumentParser.parse_args
+
+    def spy(self, *a, **kw):
+        ns = real(self, *a, **kw)
+        seen["ns"] = ns
+        raise SystemExit(0)
+    monkeypatch.setattr(argparse.ArgumentParser, "parse_args", spy)
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["ns"].workload == "llama3-70b-slice" and seen["ns"].k == 3 and seen["ns"].gpus == 1
+
+
+def test_traffic_file_is_refused_for_another_workload(bench, tmp_path, monkeypatch):
+    import json
+    (tmp_path / "profiles").mkdir()
+    json.dump({"_meta": {"workload": "llama3-8b", "k": 2}, "f2_cols_fwd": {"hbm_bytes_per_launch": 5.0}},
+              open(tmp_path / "profiles" / "traffic_latest.json", "w"))
+    monkeypatch.setattr(bench, "REPO", tmp_path)
+    assert bench.load_traffic("llama3-8b", 2, "f2_cols_fwd") == 5.0
+    assert bench.load_traffic("llama3-70b-slice", 3, "f2_cols_fwd") is None
+    assert bench.load_traffic("llama3-8b", 3, "f2_cols_fwd") is None
+
+
+def test_gpus_n_outside_torchrun_starts_the_ranks_as_a_child(bench, monkeypatch):
+    """`python bench.py --gpus 8` must not die with a usage message (the driver's SCALE run):
+    it spawns torch.distributed.run as a CHILD before touching the GPU."""
+    import subprocess
+    import sys
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_lpt_partition_is_balanced_and_deterministic():

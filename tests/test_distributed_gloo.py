@@ -51,6 +51,12 @@ def test_two_rank_merge_equals_single_process(tmp_path, monkeypatch):
     two = tmp_path / "two"
     two.mkdir()
     cfg2 = gi.write_cli_model(two)
+    # a part file left by an earlier, crashed run (other partition): must not be assembled
+    from safetensors.torch import save_file
+    (two / "merged").mkdir()
+    stale_name = sorted(gi.CLI_SHARDS)[0]
+    victim = gi.CLI_SHARDS[stale_name][0][0]
+    save_file({victim: torch.full((2, 2), 7.0)}, str(two / "merged" / f".part-1-{stale_name}"))
     port = free_port()
     procs = []
     for r in range(2):

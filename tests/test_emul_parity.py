@@ -166,3 +166,36 @@ def test_misaligned_inputs_take_the_elementwise_path(engine):
     out_a, rep_a = engine.merge_layer([ft0, ft1], [base.clone(), base.clone()], [0.3, 0.5], base.clone())
     assert rep_u.branches == rep_a.branches == ["slerp"]
     assert torch.equal(out_u, out_a)
+
+
+def test_non_finite_delta_norm_is_an_error_not_a_hang(engine):
+    """K >= 2 with a NaN (or Inf) element: no pair can ever be formed and the reference's
+    tournament loop spins forever (fast_fourier.py:171-254); the library returns an error."""
+    base = torch.randn(16, 16).to(torch.bfloat16)
+    fts = [(base.float() + 0.01 * torch.randn(16, 16)).to(torch.bfloat16) for _ in range(3)]
+    fts[1][2, 3] = float("nan")
+    for k in (2, 3):
+        with pytest.raises(ValueError, match="Non-finite delta norm in model.layers.0.w"):
+            engine.merge_layer(fts[:k], [base] * k, [0.3, 0.5, 0.2][:k], base, layer_name="model.layers.0.w")
+    fts[1][2, 3] = float("inf")
+    with pytest.raises(ValueError, match="Non-finite delta norm"):
+        engine.merge_layer(fts[:2], [base] * 2, [0.3, 0.5], base)
+    # the context stays usable
+    fts[1][2, 3] = 0.0
+    out, rep = engine.merge_layer(fts[:2], [base] * 2, [0.3, 0.5], base)
+    assert rep.branches == ["slerp"] and not torch.isnan(out.float()).any()
+
+
+def test_mixed_input_dtypes_are_promoted_not_demoted(engine):
+    """fp32 base next to bf16 finetunes (and mixed bf16/fp32 finetunes): the reference upcasts
+    everything to fp32 (base.py:128-131); demoting the base to bf16 changed 93 % of the outputs."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(11)
+    base32 = torch.randn(64, 128, generator=g) * 0.02                     # NOT bf16-representable
+    fts = [(base32 + torch.randn(64, 128, generator=g) * s_).to(torch.bfloat16) for s_ in (0.002, 0.003)]
+    for f_list in (fts, [fts[0], fts[1].float()]):
+        ref = so.merge_layer(f_list, [base32, base32], so.ALPHAS[:2], base32)
+        out, rep = engine.merge_layer(f_list, [base32, base32], so.ALPHAS[:2], base32)
+        assert rep.branches == ["slerp"]
+        total, resid = pc.spectral_residual(out.float(), ref.float())
+        assert resid < 1e-4 and (out.view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 0.02

@@ -235,3 +235,27 @@ def test_cli_aborts_on_missing_model(tmp_path, emul):
 def test_shard_alias_package():
     import importlib
     assert importlib.import_module("shard.__main__").cli.name == "cli"
+
+
+def test_unsupported_lengths_fail_before_any_layer_is_merged(tmp_path, emul):
+    """A block tensor with a transform length the library cannot do (here 2 * 16411, above the
+    longest transform) stops the run in initialize(), before any shard has been written."""
+    from shardmerge_amd.__main__ import cli
+    cfg_path = gi.write_cli_model(tmp_path)
+    cfg = MergeConfig.from_yaml(cfg_path)
+    victim = "model.layers.1.self_attn.q_proj.weight"
+    for uri in ["org/base", "org/ft1", "org/ft2"]:
+        d = cfg.storage_path / uri
+        shard = json.load(open(d / "model.safetensors.index.json"))["weight_map"][victim]
+        with safe_open(str(d / shard), framework="pt") as f:
+            tens = {k: f.get_tensor(k) for k in f.keys()}
+        tens[victim] = torch.zeros(2, 40009, dtype=torch.bfloat16)
+        save_file(tens, str(d / shard), metadata={"format": "pt"})
+    if emul.lib.length_supported(40009):
+        pytest.skip("every length is supported by this build")
+    merger = FourierMerge(config=cfg, index_manager=LocalModelIndex(cfg.storage_path), engine=emul)
+    with pytest.raises(NotImplementedError, match="model.layers.1.self_attn.q_proj.weight"):
+        asyncio.run(merger.initialize())
+    res = CliRunner().invoke(cli, ["merge", str(cfg_path)])
+    assert res.exit_code != 0
+    assert not list((tmp_path / "merged").glob("*.safetensors"))          # nothing was written

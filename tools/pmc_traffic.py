@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs into per-kernel HBM traffic.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [workload_id k]
+
+The optional workload stamp (bench.py --workload / --k of the profiled command) goes into
+"_meta": bench.py only quotes a traffic figure whose stamp matches its own run.
 
 Units and corrections as MI355X_MICROARCH.md (HBM section) prescribes: the counters
 are in KiB... (rocprofv3 reports FETCH_SIZE/WRITE_SIZE in kilobytes); on gfx950
@@ -51,8 +54,12 @@ def main():
         rec["write_bytes"] += w * 1024.0
     for rec in out.values():
         rec["hbm_bytes_per_launch"] = (rec["fetch_bytes"] + rec["write_bytes"]) / rec["launches"]
+    printable = dict(out)
+    if len(sys.argv) > 5:
+        out["_meta"] = {"workload": sys.argv[4], "k": int(sys.argv[5]),
+                        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes (tools/traffic_run.sh)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
+    for k, v in sorted(printable.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
         print(f"{k:20s} launches {v['launches']:5d}  fetch {v['fetch_bytes']/1e9:8.3f} GB  write {v['write_bytes']/1e9:8.3f} GB  per launch {v['hbm_bytes_per_launch']/1e6:9.2f} MB")
 
 
