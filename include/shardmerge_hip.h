@@ -71,6 +71,8 @@ typedef struct {
     double cutoff_threshold, cull_threshold;
     double dot, s00, s01, s11;
     uint64_t n_slerp;
+    double t;          /* slerp fraction used (fast_fourier.py:234: weights NOT swapped with a/b, quirk Q4) */
+    double cull_pct;   /* cull fraction used (halved every tournament round, fast_fourier.py:254) */
 } smhip_blend_info;
 int smhip_interpolate_fft_components(smhip_ctx* ctx, const float* f0, const float* f1, int rows, int cols,
                                      double t, double t_sum, double cutoff_pct, double cull_pct, int interp_imag,

@@ -68,7 +68,7 @@ def l2norm(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # A6 - slerp on the gathered (1-D, masked) real parts
 # --------------------------------------------------------------------------
-def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float) -> torch.Tensor:
+def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float, info: Optional[dict] = None) -> torch.Tensor:
     """reference shard/tensor/functions.py:24-43.
 
     Note the reference's quirk: the cosine ``c`` is taken between
@@ -77,6 +77,8 @@ def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float) -> torch.Tensor:
     """
     c = torch.sum(v0 * v1) / (l2norm(v0) * l2norm(v1))
     c = torch.clamp(c, -1.0, 1.0)
+    if info is not None:
+        info["dot"] = float(c)
     theta = torch.acos(c) * t
     rel = v1 - v0 * c
     if NORM_MODE == "exact":
@@ -124,6 +126,10 @@ class BlendTrace:
     n_sum: int = 0
     n_rest: int = 0
     n_culled: int = 0
+    dot: float = 0.0                      # clamped cosine of the slerp class (functions.py:36-37)
+    t: float = 0.0                        # slerp fraction the caller passed
+    cull_pct: float = 0.0                 # cull fraction the caller passed
+    culled_mask: Optional[torch.Tensor] = None   # bool, full spectrum: bins zeroed by the cull
 
 
 def kth_smallest(values: torch.Tensor, fraction: float) -> float:
@@ -168,12 +174,14 @@ def interpolate_fft_components(
     sel_rest = ~sel_slerp & ~sel_sum
     v0_bigger = m0 > m1
 
-    out.real[sel_slerp] = slerp(r0[sel_slerp], r1[sel_slerp], t)
+    sl_info: dict = {}
+    out.real[sel_slerp] = slerp(r0[sel_slerp], r1[sel_slerp], t, sl_info)
     out.real[sel_sum] = r0[sel_sum] + t_sum * r1[sel_sum]
     out.real[sel_rest] = torch.where(v0_bigger[sel_rest], r0[sel_rest], r1[sel_rest])
 
     cull_thr = 0.0
     n_culled = 0
+    kill = None
     if cull_pct > 0:
         mag, _ = torch.sort(out.real.abs().ravel(), descending=False)
         cull_thr = mag[int(len(mag) * cull_pct)].item()
@@ -191,6 +199,10 @@ def interpolate_fft_components(
         trace.n_sum = int(sel_sum.sum())
         trace.n_rest = int(sel_rest.sum())
         trace.n_culled = n_culled
+        trace.dot = sl_info.get("dot", 0.0)
+        trace.t = float(t)
+        trace.cull_pct = float(cull_pct)
+        trace.culled_mask = kill.clone() if kill is not None else None
 
     if interp_imag:
         g0 = fft_transform(f0.imag)
@@ -330,6 +342,8 @@ class LayerTrace:
     pairs: List[Tuple[int, int]] = field(default_factory=list)
     target_norm: float = 0.0
     merged_delta: Optional[torch.Tensor] = None          # fp32, before add-back
+    steps: List[Optional[BlendTrace]] = field(default_factory=list)   # per pairing step; None: carry / add / arith
+    step_norms: List[Tuple[float, float]] = field(default_factory=list)   # (||a||, ||b||) after the swap
 
 
 def merge_layer(
@@ -343,11 +357,18 @@ def merge_layer(
     cutoff_pct: float = 0.08,
     trace: Optional[LayerTrace] = None,
     layer_name: str = "layer",
+    _mutation: Optional[str] = None,
 ) -> torch.Tensor:
     """The block-tensor branch of FourierMerge._merge_layer,
     reference shard/merge/fast_fourier.py:132-276 (+ base.py:117-137 for the
     deltas), with the disk cache replaced by a dict.  Inputs are the tensors the
     index would hand out for the models that pass ``use_layer_index``.
+
+    ``_mutation`` selects a DELIBERATELY WRONG variant ("keep_cull_pct": the cull
+    fraction is not halved per round, :254; "swap_weights": weights follow the a/b
+    swap, against quirk Q4 :212-215; "sum_weights": the merged weight is a_w + b_w
+    instead of their mean, :247).  Only tests/ use it, to show that the K >= 3
+    parity checks can tell such a slip from the reference's own rounding chaos.
     """
     k = len(finetunes)
     names = list(names) if names is not None else [f"model{i}" for i in range(k)]
@@ -383,6 +404,8 @@ def merge_layer(
                 if trace is not None:
                     trace.branches.append("carry")
                     trace.pairs.append((x, -1))
+                    trace.steps.append(None)
+                    trace.step_norms.append((0.0, 0.0))
                 continue
             a_name, b_name = stack[x], stack[y]
             a_w, b_w = weights[x], weights[y]
@@ -392,9 +415,12 @@ def merge_layer(
                 a, b = b, a
                 a_name, b_name = b_name, a_name
                 na, nb = nb, na                        # Q4: weights not swapped
+                if _mutation == "swap_weights":
+                    a_w, b_w = b_w, a_w
             ca = abs(na / target_norm)
             cb = abs(nb / target_norm)
             ratio = cb / (ca + 1e-10)
+            btrace = None
             if ca < 1e-6:
                 merged = a + b
                 kind = "add"
@@ -405,20 +431,24 @@ def merge_layer(
                 kind = "arith"
             else:
                 prop = a_w / (a_w + b_w)
+                btrace = BlendTrace() if trace is not None else None
                 merged, _, _ = merge_tensors_fft2_slerp(
-                    a, b, t=prop, t_sum=1.0, cutoff_pct=cutoff_pct, cull_pct=cull_pct
+                    a, b, t=prop, t_sum=1.0, cutoff_pct=cutoff_pct, cull_pct=cull_pct, trace=btrace
                 )
                 merged = merged * target_norm
                 kind = "slerp"
             if trace is not None:
                 trace.branches.append(kind)
                 trace.pairs.append((x, y))
+                trace.steps.append(btrace)
+                trace.step_norms.append((na, nb))
             new_name = name_hash(f"{a_name}_{b_name}")
             nxt_stack.append(new_name)
-            nxt_weights.append((a_w + b_w) / 2.0)
+            nxt_weights.append((a_w + b_w) if _mutation == "sum_weights" else (a_w + b_w) / 2.0)
             store[new_name] = merged
         stack, weights = nxt_stack, nxt_weights
-        cull_pct = cull_pct / 2.0
+        if _mutation != "keep_cull_pct":
+            cull_pct = cull_pct / 2.0
 
     result = store[stack[0]]
     if trace is not None:

@@ -26,6 +26,7 @@ class BlendInfo(C.Structure):
         ("cutoff_threshold", C.c_double), ("cull_threshold", C.c_double),
         ("dot", C.c_double), ("s00", C.c_double), ("s01", C.c_double), ("s11", C.c_double),
         ("n_slerp", C.c_uint64),
+        ("t", C.c_double), ("cull_pct", C.c_double),
     ]
 
 

@@ -620,6 +620,7 @@ class Pipeline {
         info->dot = have_consts ? c.dot : 0.0;
         info->s00 = have_consts ? c.s00 : 0.0; info->s01 = have_consts ? c.s01 : 0.0; info->s11 = have_consts ? c.s11 : 0.0;
         info->n_slerp = have_consts ? c.n_slerp : 0;
+        info->t = 0.0; info->cull_pct = 0.0;        // filled by callers that know them
     }
 
     static unsigned long long pct_index(unsigned long long len, double pct) {
@@ -701,6 +702,7 @@ class Pipeline {
         spectral_blend(g, BLEND_SLERP, t, t_sum, cutoff_pct, cull_pct, 1, true, have_cull);
         if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, po))) return rc;
         read_blend_info(info, cutoff_pct > 0, have_cull, true);
+        if (info) { info->t = t; info->cull_pct = cull_pct; }
         return check_flags(true, false);
     }
 
@@ -1060,6 +1062,7 @@ class Pipeline {
                         }
                     }
                 }
+                if (branch == SMHIP_BRANCH_SLERP) { info.t = a_w / (a_w + b_w); info.cull_pct = cull_pct; }
                 if (step < SMHIP_MAX_PAIRS) { rp.step_branch[step] = branch; rp.step_info[step] = info; }
                 ++step;
                 for (size_t q = 0; q < inter_.size(); ++q)     // inputs that were intermediates are dead now
@@ -1091,8 +1094,11 @@ class Pipeline {
             rp.merged_delta_norm = nm;
         }
         rc = check_flags(true, true, &rp.nan_ifft, &rp.nan_final);
-        if (deferred_step >= 0 && deferred_step < SMHIP_MAX_PAIRS)
+        if (deferred_step >= 0 && deferred_step < SMHIP_MAX_PAIRS) {
+            const double t_keep = rp.step_info[deferred_step].t, c_keep = rp.step_info[deferred_step].cull_pct;
             read_blend_info(&rp.step_info[deferred_step], deferred_cut, deferred_cull, true, /*published=*/true);
+            rp.step_info[deferred_step].t = t_keep; rp.step_info[deferred_step].cull_pct = c_keep;
+        }
         return rc;
     }
 
@@ -1164,6 +1170,7 @@ class Pipeline {
             be.template launch<KCull>(sgrid, 256, slds, cp, stream);
         }
         read_blend_info(info, mode == BLEND_SLERP && cutoff_pct > 0, have_cull, mode == BLEND_SLERP);
+        if (info) { info->t = t; info->cull_pct = cull_pct; }
         JoinParams jp;
         jp.n = total; jp.chunks = 8; jp.full = (cf2*)out_spec;
         if (!do_imag) {

@@ -46,10 +46,13 @@ class BlendReport:
     s01: float = 0.0
     s11: float = 0.0
     n_slerp: int = 0
+    t: float = 0.0
+    cull_pct: float = 0.0
 
     @classmethod
     def from_c(cls, bi: BlendInfo) -> "BlendReport":
-        return cls(bi.cutoff_threshold, bi.cull_threshold, bi.dot, bi.s00, bi.s01, bi.s11, int(bi.n_slerp))
+        return cls(bi.cutoff_threshold, bi.cull_threshold, bi.dot, bi.s00, bi.s01, bi.s11, int(bi.n_slerp),
+                   bi.t, bi.cull_pct)
 
 
 @dataclass

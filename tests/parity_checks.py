@@ -128,6 +128,95 @@ def models_in_window(case):
     return tensors, use, cfg, lname
 
 
+# ---- K >= 3: what CAN be compared tightly -------------------------------------------------------
+# From the second tournament round on, an input is an intermediate whose spectrum holds the bins
+# the previous round culled.  In the reference those bins come back from its ifft -> fft round
+# trip as +-1e-7 rounding noise, and the round takes its sign-agreement decisions, its 8 %
+# quantile (which lands INSIDE the noise values: >= 16 % of the concatenated magnitudes are
+# noise) and therefore its slerp-class membership on that noise (oracle/chaos_probe.py).  That
+# part is not reproducible by anything but a bit-identical FFT.  Everything else is:
+#   * the pairing, the branch, t (quirk Q4), the round's cull fraction        -> exact
+#   * first-round thresholds / class counts / cosine                            -> as for K = 2
+#   * later rounds: the cutoff threshold must be noise-level; the cull threshold, the class
+#     count and the cosine move only by what the noise bins' membership moves them (measured
+#     against the real reference: <= 3e-2, 3e-2, 2e-2) - a wrong cull fraction moves the cull
+#     threshold by 2x, a wrong weight moves t
+#   * the merged delta's spectrum OUTSIDE the bins that earlier rounds culled (and outside the
+#     bins whose final cull decision differs because the cull threshold moved: those must sit
+#     on the threshold and be few) agrees to ~1e-3 (K = 3: the slerp constants see the noise
+#     bins' membership) / 1e-4 (K = 4 goldens); INSIDE, only the statistical floor holds.
+LATER_ROUND_CULL_TOL = 5e-2
+LATER_ROUND_NSLERP_TOL = 3e-2
+LATER_ROUND_DOT_TOL = 2e-2
+OUTSIDE_CULLED_TOL = 2.5e-3
+
+
+def check_layer_steps(rep, tr, numel, reported_fields=True):
+    """Every pairing step of the HIP path's report against the oracle's trace.
+    reported_fields=False skips t and the cull fraction (values the library merely reports
+    back) so that a test can show the MEASURED quantities alone catch a slip."""
+    assert rep.branches == tr.branches
+    assert [(s[0], s[1]) for s in rep.steps] == tr.pairs
+    k = len(rep.delta_norms)
+    first_round_steps = (k + 1) // 2            # later steps take at least one intermediate as input
+    first_cut = None
+    for i, (info, bt) in enumerate(zip(rep.infos, tr.steps)):
+        if bt is None or tr.branches[i] != "slerp":
+            continue
+        if reported_fields:
+            assert abs(info.t - bt.t) <= 1e-12, f"step {i}: t {info.t} vs {bt.t} (weights / quirk Q4)"
+            assert info.cull_pct == bt.cull_pct, f"step {i}: cull fraction {info.cull_pct} vs {bt.cull_pct}"
+        if i < first_round_steps:
+            first_cut = bt.cutoff_threshold if first_cut is None else first_cut
+            assert abs(info.cutoff_threshold - bt.cutoff_threshold) <= 1e-5 * bt.cutoff_threshold + 1e-30, f"step {i} cutoff"
+            assert abs(info.cull_threshold - bt.cull_threshold) <= 5e-5 * bt.cull_threshold + 1e-30, f"step {i} cull"
+            assert abs(info.n_slerp - bt.n_slerp) <= 4 + 1e-4 * bt.n_slerp, f"step {i} n_slerp"
+            assert abs(info.dot - bt.dot) <= 1e-4, f"step {i} dot"
+        else:
+            if first_cut:
+                assert info.cutoff_threshold < 1e-3 * first_cut and bt.cutoff_threshold < 1e-3 * first_cut, \
+                    f"step {i}: the cutoff threshold of a later round lies in the culled bins' noise"
+            assert abs(info.cull_threshold - bt.cull_threshold) <= LATER_ROUND_CULL_TOL * bt.cull_threshold, \
+                f"step {i} cull threshold {info.cull_threshold} vs {bt.cull_threshold}"
+            assert abs(info.n_slerp - bt.n_slerp) <= LATER_ROUND_NSLERP_TOL * bt.n_slerp, f"step {i} n_slerp"
+            assert abs(info.dot - bt.dot) <= LATER_ROUND_DOT_TOL, f"step {i} dot {info.dot} vs {bt.dot}"
+
+
+def masked_spectral_check(delta, tr, tol_outside=OUTSIDE_CULLED_TOL):
+    """Spectrum of (delta - oracle's merged delta), split by the bins earlier rounds culled.
+    Returns (relative error outside, relative error inside, number of final-cull flips)."""
+    ref = tr.merged_delta.double()
+    d = delta.double().cpu() - ref
+    dims = tuple(range(ref.ndim))
+    D, Rf, Hf = torch.fft.fftn(d), torch.fft.fftn(ref), torch.fft.fftn(delta.double().cpu())
+    slerp_steps = [i for i, b in enumerate(tr.steps) if b is not None and b.culled_mask is not None]
+    assert len(slerp_steps) >= 2
+    union = torch.zeros(ref.shape, dtype=torch.bool)
+    for i in slerp_steps[:-1]:
+        union |= tr.steps[i].culled_mask.reshape(ref.shape)
+    mirror = lambda m: torch.roll(torch.flip(m, dims=dims), shifts=tuple([1] * len(dims)), dims=dims)
+    union |= mirror(union)
+    # final cull: a bin zeroed on one side only must sit on the (moved) threshold
+    last = tr.steps[slerp_steps[-1]]
+    scale = tr.target_norm
+    thr = last.cull_threshold * scale
+    zero_ref = Rf.real.abs() < 1e-3 * thr
+    zero_hip = Hf.real.abs() < 1e-3 * thr
+    flips = (zero_ref ^ zero_hip) & ~union
+    mag = torch.where(zero_ref, Hf.real.abs(), Rf.real.abs())
+    assert bool(((mag[flips] - thr).abs() <= 1.5 * LATER_ROUND_CULL_TOL * thr).all()), \
+        "a bin culled on one side only does not sit on the cull threshold"
+    n_flips = int(flips.sum())
+    assert n_flips <= 16 + 2 * LATER_ROUND_CULL_TOL * 0.5 * ref.numel() * last.cull_pct, f"{n_flips} final-cull flips"
+    keep = ~union & ~flips & ~mirror(flips)
+    e2 = (D.real ** 2 + D.imag ** 2)
+    r2 = (Rf.real ** 2 + Rf.imag ** 2)
+    outside = math.sqrt(float(e2[keep].sum()) / float(r2[keep].sum()))
+    inside = math.sqrt(float(e2[union].sum()) / max(float(r2[union].sum()), 1e-300)) if bool(union.any()) else 0.0
+    assert outside <= tol_outside, f"outside the culled bins the merged delta differs by {outside:.2e}"
+    return outside, inside, n_flips
+
+
 def check_layer(engine, golden, case):
     tensors, use, cfg, lname = models_in_window(case)
     fts = [tensors[m["model"]] for m in use]
@@ -155,6 +244,9 @@ def check_layer(engine, golden, case):
         assert d_resid < 2e-5, f"merged delta differs by {d_resid:.2e} beyond the tie bins"
         assert total <= 2.5 * floor + 1e-4, f"{total:.2e} vs reference self-floor {floor:.2e}"
     else:
-        # later rounds decide on rounding noise in the reference (module docstring)
+        # later rounds decide on rounding noise in the reference (module docstring): the total
+        # is bounded by the reference's own floor, everything reproducible is compared tightly
         assert total <= 2.5 * floor + 1e-4, f"{total:.2e} vs reference self-floor {floor:.2e}"
+        masked_spectral_check(delta, tr)
+    check_layer_steps(rep, tr, out.numel())
     return rep

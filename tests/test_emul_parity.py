@@ -199,3 +199,73 @@ def test_mixed_input_dtypes_are_promoted_not_demoted(engine):
         assert rep.branches == ["slerp"]
         total, resid = pc.spectral_residual(out.float(), ref.float())
         assert resid < 1e-4 and (out.view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 0.02
+
+
+# ---- K >= 3: the checks are sharp enough to tell a slip from the reference's own chaos ----------
+def _layer_run(engine, case, mutation=None):
+    from oracle import spectral_oracle as so
+    tensors, use, cfg, lname = pc.models_in_window(case)
+    fts = [tensors[m["model"]] for m in use]
+    bases = [tensors[m["base"]] for m in use]
+    alphas = [m["alpha"] for m in use]
+    tr = so.LayerTrace()
+    so.merge_layer(fts, bases, alphas, tensors[cfg["output_base_model"]], trace=tr, _mutation=mutation)
+    out, rep, delta = engine.merge_layer(fts, bases, alphas, tensors[cfg["output_base_model"]], want_delta=True)
+    return rep, tr, delta
+
+
+@pytest.mark.parametrize("cid", ["layer_k3", "layer_k3_swap", "layer_k4"])
+def test_k3_steps_and_unculled_spectrum_match_the_oracle(engine, cid):
+    case = [c for c in gi.LAYER_CASES if c["id"] == cid][0]
+    rep, tr, delta = _layer_run(engine, case)
+    pc.check_layer_steps(rep, tr, delta.numel())
+    outside, inside, flips = pc.masked_spectral_check(delta, tr)
+    assert inside > 3 * outside            # the irreproducible part really is confined to the culled bins
+
+
+@pytest.mark.parametrize("cid,mutation", [("layer_k3", "keep_cull_pct"), ("layer_k4", "keep_cull_pct"),
+                                          ("layer_k3", "sum_weights"),     # (K = 4: both weights double, t is unchanged)
+                                          ("layer_k3_swap", "swap_weights"), ("layer_k4", "swap_weights")])
+def test_k3_checks_catch_a_wrong_round2(engine, cid, mutation):
+    """Against an oracle with a deliberate slip (cull fraction not halved, merged weight not
+    averaged, weights swapped with a/b - quirk Q4) the same checks must FAIL, on measured
+    quantities alone (the library's self-reported t / cull fraction are not consulted):
+    the old bound - 2.5 x the reference's chaos floor on the output - let all of these pass."""
+    case = [c for c in gi.LAYER_CASES if c["id"] == cid][0]
+    rep, tr_bad, delta = _layer_run(engine, case, mutation)
+    caught = 0
+    for check in (lambda: pc.check_layer_steps(rep, tr_bad, delta.numel(), reported_fields=False),
+                  lambda: pc.masked_spectral_check(delta, tr_bad)):
+        try:
+            check()
+        except AssertionError:
+            caught += 1
+    assert caught >= 1, f"{mutation} on {cid} went unnoticed"
+    with pytest.raises(AssertionError):
+        pc.check_layer_steps(rep, tr_bad, delta.numel())        # and the reported fields say so directly
+
+
+def test_nan_inf_policy_in_the_inverse_row_pass(engine):
+    """K = 2: the add-back happens inside the inverse row pass (its group-of-8 NaN/Inf screen
+    and the packed bf16 conversion).  A NaN in output_base_model's tensor is zeroed and counted
+    (fast_fourier.py:270-271), an Inf raises the reference's error (:273-274)."""
+    g = torch.Generator().manual_seed(21)
+    base = (torch.randn(64, 256, generator=g) * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(64, 256, generator=g) * s_).to(torch.bfloat16) for s_ in (0.002, 0.003)]
+    clean, rep0 = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)
+    bo = base.clone()
+    bo[5, 17] = float("nan")
+    bo[63, 255] = float("nan")
+    out, rep = engine.merge_layer(fts, [base, base], [0.3, 0.5], bo)
+    out, clean = out.cpu(), clean.cpu()
+    assert rep.nan_final == 2 and rep.nan_ifft == 0
+    assert out[5, 17] == 0 and out[63, 255] == 0 and not torch.isnan(out.float()).any()
+    mask = torch.ones(64, 256, dtype=torch.bool)
+    mask[5, 17] = mask[63, 255] = False
+    assert torch.equal(out[mask], clean[mask])                     # nothing else moved
+    bo = base.clone()
+    bo[7, 3] = float("-inf")
+    with pytest.raises(ValueError, match="Inf in merged tensor for model.layers.1.mlp"):
+        engine.merge_layer(fts, [base, base], [0.3, 0.5], bo, layer_name="model.layers.1.mlp")
+    out2, _ = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)     # the context stays usable
+    assert torch.equal(out2.cpu(), clean)

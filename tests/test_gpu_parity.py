@@ -143,16 +143,22 @@ def _smooth(n):
     return [n == 1]
 
 
-def test_layer_k3_vs_oracle(engine):
-    base, fts = so.synthetic_layer(1024, 1024, 3, seed=5000)
+@pytest.mark.parametrize("k", [3, 4])
+def test_layer_k3_k4_vs_oracle(engine, k):
+    """1024 x 1024, K = 3 / 4: every step's thresholds, class counts, cosine, t and cull fraction
+    against the oracle trace, and the merged delta's spectrum outside the bins that earlier rounds
+    culled (tests/parity_checks.py: what is and is not reproducible from round 2 on)."""
+    base, fts = so.synthetic_layer(1024, 1024, k, seed=5000)
     tr = so.LayerTrace()
     with so.exact_norms():
-        ref = so.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, trace=tr)
-    out, rep = engine.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base)
-    assert rep.branches == tr.branches
-    # round 2 of the reference decides on rounding noise (oracle/chaos_probe.py): its own
-    # reproducibility floor on the bf16 output is ~1.5e-3 at every size
-    assert so.rel_err(out.cpu().float(), ref.float()) < 5e-3
+        ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    pc.check_layer_steps(rep, tr, out.numel())
+    outside, inside, flips = pc.masked_spectral_check(delta.cpu(), tr)
+    print(f"K={k}: outside the culled bins {outside:.2e}, inside {inside:.2e}, final-cull flips {flips}")
+    # the irreproducible part (the reference's own chaos floor on the bf16 output: 1.6e-3 at
+    # K = 3, 3.1e-2 at K = 4, every size) bounds the total
+    assert so.rel_err(out.cpu().float(), ref.float()) < (5e-3 if k == 3 else 8e-2)
 
 
 # ---- full-size properties (8192 x 8192: BASELINE's shape) ---------------------------
@@ -304,3 +310,121 @@ def test_cli_end_to_end_on_device(tmp_path, golden):
                     assert so.rel_err(got.float(), ref.float()) < 2e-3
                 else:
                     assert torch.equal(got, ref)
+
+
+# ---- policy and edge paths ON THE DEVICE (the emulator tier runs the same checks with g++;
+# here they go through the gfx950 code: real atomics for the sticky overflow word, the
+# and+max NaN screen with v_cvt_pk_bf16_f32, the run-time planned / element-wise kernels) -----
+from tests import test_emul_parity as emul_tier      # noqa: E402  (functions take the engine as an argument)
+
+_SHARED = [emul_tier.test_inf_raises_like_reference, emul_tier.test_nan_is_zeroed, emul_tier.test_heavy_ties,
+           emul_tier.test_unsupported_length_is_loud, emul_tier.test_non_finite_delta_norm_is_an_error_not_a_hang,
+           emul_tier.test_mixed_input_dtypes_are_promoted_not_demoted, emul_tier.test_nan_inf_policy_in_the_inverse_row_pass]
+
+
+@pytest.mark.parametrize("check", _SHARED, ids=lambda f: f.__name__[5:])
+def test_policy_on_device(engine, check):
+    check(engine)
+
+
+def test_candidate_list_overflow_falls_back_on_device(engine, golden):
+    emul_tier.test_candidate_list_overflow_falls_back(engine, golden)
+
+
+@pytest.mark.parametrize("cid", ["layer_k3", "layer_k3_swap", "layer_k4"])
+def test_k3_steps_and_unculled_spectrum_on_device(engine, cid):
+    emul_tier.test_k3_steps_and_unculled_spectrum_match_the_oracle(engine, cid)
+
+
+@pytest.mark.parametrize("cid,mutation", [("layer_k3", "keep_cull_pct"), ("layer_k4", "keep_cull_pct"),
+                                          ("layer_k3", "sum_weights"), ("layer_k3_swap", "swap_weights")])
+def test_k3_checks_catch_a_wrong_round2_on_device(engine, cid, mutation):
+    emul_tier.test_k3_checks_catch_a_wrong_round2(engine, cid, mutation)
+
+
+def test_misaligned_device_inputs_take_the_elementwise_path(engine):
+    """A device view that is not 16-byte aligned must run the run-time planned, element-wise
+    kernels (`vec = 0`) and give the same bits as the aligned copy."""
+    g = torch.Generator().manual_seed(9)
+    big = (torch.randn(3 + 64 * 1024, generator=g) * 0.01).to(torch.bfloat16).cuda()
+    base = big[3:3 + 32 * 1024].view(32, 1024)              # 6-byte offset into the allocation
+    assert base.data_ptr() % 16 != 0 and base.is_contiguous()
+    ft0 = (base.float() + torch.randn(32, 1024, generator=g).cuda() * 0.002).to(torch.bfloat16)
+    ft1 = (base.float() + torch.randn(32, 1024, generator=g).cuda() * 0.003).to(torch.bfloat16)
+    out_u, rep_u = engine.merge_layer([ft0, ft1], [base, base], [0.3, 0.5], base)
+    out_a, rep_a = engine.merge_layer([ft0, ft1], [base.clone(), base.clone()], [0.3, 0.5], base.clone())
+    assert rep_u.branches == rep_a.branches == ["slerp"]
+    assert (out_u != out_a).float().mean().item() < 1e-3     # two plans (static / run-time): ulps apart
+    assert so.rel_err(out_u.float().cpu(), out_a.float().cpu()) < 1e-5
+
+
+# ---- the BASELINE configs' REAL tensor shapes against the oracle (slow: the oracle's two sorts) ----
+def _oracle_threads():
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    torch.set_num_threads(max(1, min(16, n)))       # the sort-bound oracle is slower on hundreds of threads
+
+
+@pytest.mark.parametrize("shape", [(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336), (1024, 8192)],
+                         ids=lambda s: f"{s[0]}x{s[1]}")
+def test_real_model_shapes_k2_vs_exact_norm_oracle(engine, shape):
+    """Every 2-D block-tensor shape of Llama-3-8B / Mixtral (BASELINE configs 2, 3, 5) and the
+    1024 x 8192 of Llama-3-70B at FULL size: K = 2 merge against the oracle with exact norms."""
+    _oracle_threads()
+    rows, cols = shape
+    base, fts = so.synthetic_layer(rows, cols, 2, seed=900 + rows + cols)
+    trx = so.LayerTrace()
+    with so.exact_norms():
+        refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
+    pc.check_layer_steps(rep, trx, out.numel())
+    d_total, d_resid = pc.spectral_residual(delta.cpu(), trx.merged_delta)
+    assert d_resid < 2e-5, f"beyond the tie bins: {d_resid:.2e}"
+    assert d_total < 1e-3, f"merged delta (SURVEY 8d's stricter bar): {d_total:.2e}"
+    assert so.rel_err(out.cpu().float(), refx.float()) < 1e-3          # BASELINE: 1e-3 on the bf16 output
+    mism = (out.cpu().view(torch.int16) != refx.view(torch.int16)).float().mean().item()
+    assert mism < 0.02, f"{mism:.3%} of the bf16 outputs differ"
+
+
+def test_fullsize_8192sq_vs_reference_as_is(engine):
+    """One [8192 x 8192] K = 2 merge (the north-star micro-benchmark shape) against the oracle
+    EXACTLY as the reference is - torch's CPU norm kernel included, which is biased by -5e-3 at
+    67 M elements (oracle/norm_bias_probe.py) - and against the exact-norm oracle.  The
+    measured errors are recorded (gpurun_out/parity_fullsize.json -> profiles/)."""
+    import json
+    import os
+    import time
+    _oracle_threads()
+    base, fts = so.synthetic_layer(8192, 8192, 2, seed=1000)
+    t0 = time.time()
+    tr, trx = so.LayerTrace(), so.LayerTrace()
+    ref = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr)
+    with so.exact_norms():
+        refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    t_oracle = time.time() - t0
+    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
+    out, delta = out.cpu(), delta.cpu()
+    rec = {
+        "shape": [8192, 8192], "k": 2, "seed": 1000, "oracle_seconds_both_modes": round(t_oracle, 1),
+        "torch_threads": torch.get_num_threads(),
+        "as_is": {"out_rel_err": so.rel_err(out.float(), ref.float()), "delta_rel_err": so.rel_err(delta, tr.merged_delta),
+                  "target_norm_ref": tr.target_norm, "target_norm_hip": rep.target_norm},
+        "exact_norms": {"out_rel_err": so.rel_err(out.float(), refx.float()), "delta_rel_err": so.rel_err(delta, trx.merged_delta),
+                        "target_norm_ref": trx.target_norm},
+        "reference_self_shift": {"out": so.rel_err(ref.float(), refx.float()),
+                                 "delta": so.rel_err(tr.merged_delta, trx.merged_delta)},
+        "steps_hip": [vars(i) for i in rep.infos],
+        "steps_as_is": [{k: v for k, v in vars(b).items() if k != "culled_mask"} for b in tr.steps if b is not None],
+        "steps_exact": [{k: v for k, v in vars(b).items() if k != "culled_mask"} for b in trx.steps if b is not None],
+    }
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_fullsize.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(json.dumps({k: rec[k] for k in ("as_is", "exact_norms", "reference_self_shift")}))
+    pc.check_layer_steps(rep, trx, out.numel())
+    assert rec["exact_norms"]["delta_rel_err"] < 1e-3 and rec["exact_norms"]["out_rel_err"] < 1e-3
+    # BASELINE's tolerance (1e-3 relative on the bf16 output) against the reference as it is
+    assert rec["as_is"]["out_rel_err"] < 1e-3
+    # delta level vs the as-is reference: bounded by what the norm artefact does to the reference itself
+    assert rec["as_is"]["delta_rel_err"] < 1e-3 + 1.5 * rec["reference_self_shift"]["delta"]
