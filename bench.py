@@ -97,15 +97,26 @@ KERNEL_ALG_BYTES = {
 
 def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
     """Algorithmic bytes per tensor element summed over ALL launches of kernel `name` in one
-    K-way layer merge (K-1 pair merges; from the second round on one input of a pair is an
-    fp32 intermediate: its F1 reads 4n + 4n instead of 6n)."""
+    K-way layer merge as THIS implementation runs it (DESIGN.md section 5): K-1 pair merges;
+    floor(K/2) of them take two raw bf16 deltas; every non-final result stays in the spectral
+    domain (no inverse / forward transform between rounds: spec_norm + spec_rescale instead);
+    a raw delta that meets an intermediate (odd K) is transformed alone (row-pair F1 + F2S)."""
     pairs = max(k - 1, 1)
     raw = k // 2                                 # pairs whose two inputs are raw bf16 deltas
+    singles = (k - 2 * raw) if k >= 3 else 0     # raw deltas transformed alone
+    inter = pairs - 1                            # spectral intermediates produced and consumed
     per = KERNEL_ALG_BYTES.get(name, 0.0)
-    if name == "f1_rows_fwd":
-        return raw * 14.0 + (pairs - raw) * 16.0
-    if name in ("select_lvl2", "select_hist"):
-        return per * 2 * pairs                   # two launches per pair
+    table = {
+        "f1_rows_fwd": raw * 14.0 + singles * 8.0,     # pair: 6n in + 8n out; alone: 4n in + 4n out
+        "f2_cols_fwd": raw * 14.0,
+        "f2s_cols_fwd1": singles * 8.0,                # 4n in + Re, Im out
+        "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
+        "spec_norm": inter * 4.0,                      # Re R + Im a
+        "spec_rescale": inter * 4.0,                   # role b: Re in, Re out (role a: 8n)
+        "select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs,
+    }
+    if k >= 2 and name in table:
+        return table[name]
     return per * pairs
 
 

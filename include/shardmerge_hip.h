@@ -130,7 +130,10 @@ int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf
  *      lists (0 = default) so that the overflow fallback can be exercised;
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass and
  *      "sel_flush_always" flushes its staged candidates after every round (the
- *      mid-stream flush that only very large tensors reach otherwise). --------------- */
+ *      mid-stream flush that only very large tensors reach otherwise);
+ *      "spectral_intermediates" = 0 makes a K >= 3 tournament materialise every intermediate
+ *      (inverse transform to fp32, forward again) as round 1 of this library did, instead of
+ *      keeping it in the spectral domain (default 1). ----------------------------------- */
 int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
 
 /* ---- profiling: per-kernel device time measured with HIP events on the

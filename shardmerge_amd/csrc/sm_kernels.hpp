@@ -202,6 +202,8 @@ struct F1Params {
     int pitch4;            // T1 row pitch in float4
     int ilv;               // rows interleaved in T1 (1 or 2): element (r, k) at ((r/ilv)*pitch4 + k)*ilv + r%ilv
     int nb;                // rows (transforms) per work-group
+    size_t row_stride;     // elements between consecutive transforms' inputs (C; 2C in row-pair mode,
+                           // where "a" is row 2m and "b" row 2m+1 of ONE tensor: b's pointers are a's + C)
     int vec;               // 1: C % 8 == 0 and 16-byte aligned inputs
     cf4* t1;               // the column pass reads ilv*16 contiguous bytes per (row group, bin)
     double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
@@ -252,7 +254,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             for (int q = 0; q < NQ; ++q) {
                 const int n0 = 8 * (t + q * T);
                 ok[q] = valid && n0 < C;
-                off[q] = ok[q] ? ((size_t)row * C + n0) / 8 : 0;
+                off[q] = ok[q] ? ((size_t)row * p.row_stride + n0) / 8 : 0;
             }
             // an absent operand reads a's values instead (always there) and is masked out below
             const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
@@ -318,7 +320,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
             for (int q = 0; q < NQ; ++q) {
                 const int n0 = 8 * (t + q * T);
                 ok[q] = valid && n0 < C;
-                off[q] = ok[q] ? (size_t)row * C + n0 : 0;
+                off[q] = ok[q] ? (size_t)row * p.row_stride + n0 : 0;
             }
             auto load_signal = [&](const SigDesc& sg, float* dst, double& ss) {
                 if (!sg.x) {
@@ -376,7 +378,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
                 const int n = t + q * T;
                 float va = 0.f, vb = 0.f;
                 if (valid && n < C) {
-                    const size_t off = (size_t)row * C + n;
+                    const size_t off = (size_t)row * p.row_stride + n;
                     va = load_sig1(p.a, off);
                     vb = load_sig1(p.b, off);
                 }
@@ -632,6 +634,150 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     }
 }
 
+// bins per work-group of the column passes for a plan with T threads per transform
+// (measured on MI355X: 1024-thread work-groups lose more than their wider row segments
+//  gain - 8192^2: F2 382 -> 415 us, I1 164 -> 203 us - so the target is 512 threads)
+#ifndef SM_COL_THREADS
+#define SM_COL_THREADS 512
+#endif
+constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
+// the inverse column pass measured fastest with two bins per work-group at every length
+#ifndef SM_I1_THREADS
+constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 instead when 2T is too large
+#else
+constexpr int i1_bins_for(int T) { return (SM_I1_THREADS / T) > 2 ? ((SM_I1_THREADS / T) > 16 ? 16 : (SM_I1_THREADS / T)) : 2; }
+#endif
+template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T); else return 1; }
+template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return i1_bins_for(P::T); else return 2; }
+
+// ---------------------------------------------------------------------------------
+// F2S: forward column pass of ONE signal (tournament rounds >= 2: the other input of the pair is
+// an intermediate that stayed in the spectral domain).  The row pass ran in row-pair mode
+// (F1Params::row_stride = 2C): T1[m][k] = (row 2m's bin k, row 2m+1's bin k), so one float4 holds
+// two CONSECUTIVE elements of a column.  A work-group transforms G adjacent bin columns
+// (G = the 2*BINS transforms of the two-signal kernel, same threads / LDS), reading G*16
+// contiguous bytes per row pair.  role_a: the signal is the pair's larger-norm input (writes
+// Re a, Im a), else it writes Re b only.
+// ---------------------------------------------------------------------------------
+struct F2SParams {
+    FftPlanDev plan;       // N = R (even)
+    const cf4* t1;         // [R/2][pitch4]
+    int pitch4;
+    int R, C, Cb;
+    int role_a;
+    float scale;
+    float* re; float* im;  // destination planes [Cb][R] (im unused when !role_a)
+    unsigned long long* hist;
+};
+template <class P> constexpr int f2s_groups() {
+    if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
+}
+
+template <class P, int G, class Ex>
+SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    const int T = plan_T<P>(pl), R = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
+    constexpr int XG = G >= 8 ? 1 : 8 / G;                 // work-groups that share a 128-byte line of T1
+    const int lbid = xcd_remap(ex.bid(), XG);
+    const int kbase = lbid * G;
+    if (kbase >= p.Cb) return;
+    const int nthreads = G * T;
+    const int half = R / 2;
+    uint32_t* lhist = (uint32_t*)(lds + G * LF);
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int b = tid % G, lane = tid / G;
+        const int k2 = kbase + b;
+#pragma unroll
+        for (int q = 0; q < EMAX / 2; ++q) {
+            const int m = lane + q * T;
+            cf4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < half && k2 < p.Cb) v = p.t1[(size_t)m * p.pitch4 + k2];
+            s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
+        }
+        if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
+    });
+
+    wg_fft<P>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            const float* x = comp_of<comp>(s);
+            const int b = tid % G, lane = tid / G;
+            float* la = lds + b * LF;
+#pragma unroll
+            for (int q = 0; q < EMAX / 2; ++q) {
+                const int m = lane + q * T;
+                if (m < half) { la[lpad(2 * m)] = x[2 * q]; la[lpad(2 * m + 1)] = x[2 * q + 1]; }
+            }
+        },
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            const int g = tid / T, t = tid % T;
+            const float* l = lds + g * LF;
+            float* o = comp_of<comp>(s);
+#pragma unroll
+            for (int u = 0; u < EMAX / 4; ++u) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k1 = 4 * (t + u * T) + c;
+                    if (k1 < R) o[4 * u + c] = l[lpad(k1)];
+                }
+            }
+        });
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int k2 = kbase + g;
+        if (k2 >= p.Cb) return;
+        const float sc = p.scale;
+        const uint32_t w = (uint32_t)bin_weight(k2, p.C);
+        float* dre = p.re + (size_t)k2 * R;
+        float* dim = p.im + (size_t)k2 * R;
+#pragma unroll
+        for (int u = 0; u < EMAX / 4; ++u) {
+            const int k0 = 4 * (t + u * T);
+            if (k0 + 3 < R && (R & 3) == 0) {
+                cf4 vr = {s.xr[4 * u] * sc, s.xr[4 * u + 1] * sc, s.xr[4 * u + 2] * sc, s.xr[4 * u + 3] * sc};
+                *(cf4*)(dre + k0) = vr;
+                if (p.role_a) {
+                    cf4 vi = {s.xi[4 * u] * sc, s.xi[4 * u + 1] * sc, s.xi[4 * u + 2] * sc, s.xi[4 * u + 3] * sc};
+                    *(cf4*)(dim + k0) = vi;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (k0 + c < R) {
+                        dre[k0 + c] = s.xr[4 * u + c] * sc;
+                        if (p.role_a) dim[k0 + c] = s.xi[4 * u + c] * sc;
+                    }
+                }
+            }
+            if (p.hist) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (k0 + c < R) {
+                        const uint32_t key = f2u(s.xr[4 * u + c] * sc) & 0x7fffffffu;
+                        ex.lds_atomic_add(&lhist[key >> 20], w);
+                    }
+                }
+            }
+        }
+    });
+    if (p.hist) {
+        ex.sync();
+        ex.each(st, [&](int tid, FftState&) {
+            for (int h = tid; h < HIST1_BINS; h += nthreads) {
+                const uint32_t v = lhist[h];
+                if (v) ex.global_atomic_add(&p.hist[h], (unsigned long long)v);
+            }
+        });
+    }
+}
+
 // R == 1 (1-D tensors): the column transform is the identity, so the column passes are
 // plain element-wise kernels (a 2049-work-group launch of the transform kernel for a
 // 4096-element layernorm weight cost 230 us)
@@ -670,22 +816,6 @@ SM_HD void k_f2_r1(Ex& ex, const F2Params& p) {
     }
 }
 
-// bins per work-group of the column passes for a plan with T threads per transform
-// (measured on MI355X: 1024-thread work-groups lose more than their wider row segments
-//  gain - 8192^2: F2 382 -> 415 us, I1 164 -> 203 us - so the target is 512 threads)
-#ifndef SM_COL_THREADS
-#define SM_COL_THREADS 512
-#endif
-constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
-// the inverse column pass measured fastest with two bins per work-group at every length
-#ifndef SM_I1_THREADS
-constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 instead when 2T is too large
-#else
-constexpr int i1_bins_for(int T) { return (SM_I1_THREADS / T) > 2 ? ((SM_I1_THREADS / T) > 16 ? 16 : (SM_I1_THREADS / T)) : 2; }
-#endif
-template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T); else return 1; }
-template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return i1_bins_for(P::T); else return 2; }
-
 // =====================================================================
 // I1: inverse column pass
 // =====================================================================
@@ -694,6 +824,7 @@ struct I1Params {
     const float* reR;      // Re R plane [Cb][R] (cull applied on read)
     const float* imA;      // Im plane
     const float* cull_thr; // device scalar or null: |re| < *cull_thr -> 0
+    float cull_val;        // used when cull_thr is null (0: no cull)
     int R, Cb;
     int s;                 // bin columns per work-group
     cf2* G;                // [R][pitchG]
@@ -710,7 +841,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
     const int LF = plan_lds<P>(pl);
     const int bid = xcd_remap(ex.bid(), 16 / S);      // 16 bins of 8 B share a 128-B line
     if (bid * S >= p.Cb) return;
-    const float thr = p.cull_thr ? *p.cull_thr : 0.f;
+    const float thr = p.cull_thr ? *p.cull_thr : p.cull_val;
 
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
@@ -806,7 +937,7 @@ SM_HD void k_i1_r1(Ex& ex, const I1Params& p) {
     typename Ex::template State<EmptyStateF> st;
     ex.init(st);
     const int nt = ex.nthreads();
-    const float thr = p.cull_thr ? *p.cull_thr : 0.f;
+    const float thr = p.cull_thr ? *p.cull_thr : p.cull_val;
     ex.each(st, [&](int tid, EmptyStateF&) {
         for (int k2 = ex.bid() * nt + tid; k2 < p.Cb; k2 += ex.nblocks() * nt) {
             float re = p.reR[k2];
@@ -1809,6 +1940,146 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
                 const int n = load_quad(p.reA, 4 * qi, total, 0, a);
                 load_quad(p.reB, 4 * qi, total, 0, b);
                 quad(4 * qi, a, b, n, false);
+            }
+        }
+    });
+    if (p.hist) {
+        ex.sync();
+        ex.each(st, [&](int tid, EmptyState&) {
+            for (int b = tid; b < HIST1_BINS; b += nt) {
+                const uint32_t v = lh[b];
+                if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
+            }
+        });
+    }
+}
+
+// =====================================================================
+// spectral intermediates (tournament rounds >= 2, DESIGN.md "K >= 3")
+// =====================================================================
+// A pair merge that is not the last leaves its result in the spectral domain: (Re R, Im a) with
+// the cull still to be applied.  k_spec_norm takes || post * ifft(R) ||^2 * n / post^2 =
+// sum over the FULL spectrum of |R_culled|^2 (Parseval), i.e. what the reference's torch.norm of
+// the materialised intermediate measures (fast_fourier.py:209-210).
+struct SpecNormParams {
+    const float* re; const float* im;
+    int R, C, Cb;
+    int vec4;
+    const float* thr;           // device scalar (cull threshold) or null
+    double* partials;           // [grid][2]: sum w*re_c^2, sum w*im^2
+    int chunks;
+};
+template <class Ex>
+SM_HD void k_spec_norm(Ex& ex, const SpecNormParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    const float thr = p.thr ? *p.thr : 0.f;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double sr = 0, si = 0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t qi = start + (size_t)c * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            float a[4], b[4];
+            const int n = load_quad(p.re, i0, total, p.vec4, a);
+            load_quad(p.im, i0, total, p.vec4, b);
+            float qr = 0.f, qi2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < n) {
+                    const float w = (float)weight_at(wr, i0 + e);
+                    if (!(fabsf(a[e]) < thr)) qr += w * a[e] * a[e];
+                    qi2 += w * b[e] * b[e];
+                }
+            }
+            sr += qr; si += qi2;
+        }
+        s.red[0] = sr; s.red[1] = si;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) {
+        p.partials[2 * (size_t)ex.bid()] = tot[0];
+        p.partials[2 * (size_t)ex.bid() + 1] = tot[1];
+    });
+}
+
+// Rounding-noise model.  In the reference an intermediate goes through ifft -> fft before the next
+// round uses it, so the bins its cull zeroed come back as rounding noise (measured against the
+// real reference, oracle/chaos_probe.py: Gaussian, sigma = 1.1e-7 .. 1.4e-7 of the rms bin of the
+// unit-norm spectrum), and the next round takes its sign-agreement decisions and its 8 % quantile
+// ON that noise.  Exact zeros there would change those decisions systematically (sign(0) = 0 never
+// agrees; the quantile becomes 0), so the noise is modelled: a counter-based hash of
+// (seed, element index) -> Box-Muller.  Only the statistics are reproducible by anyone - the
+// reference does not reproduce its own noise across FFT libraries.
+SM_HD uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+SM_HD float model_noise(uint32_t seed, size_t i, float sigma) {
+    const uint32_t h1 = hash_u32((uint32_t)i * 2u + 1u + seed * 0x9e3779b9u) ^ hash_u32((uint32_t)(i >> 31) + seed);
+    const uint32_t h2 = hash_u32(h1 + 0x68bc21ebu);
+    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);        // (0, 1]
+    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+    // 8 % of the reference's noise values are exact zeros (fp32 cancellation; sign(0) = 0 is its own
+    // sign class there): measured 0.094 / 0.081 / 0.076 at 256^2 / 1024^2 / 4096^2
+    if ((h2 & 0xffu) < 21u) return 0.f;
+    return sigma * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+}
+
+struct SpecRescaleParams {
+    const float* re; const float* im;   // the intermediate's planes (im may be null: role b)
+    float* dre; float* dim;             // destination planes (may alias the sources)
+    int R, C, Cb;
+    int vec4;
+    float thr;                          // cull threshold (value), applied on read
+    float scale;                        // 1 / sqrt(sum |R_c|^2 / n): unit spatial norm
+    float sigma; uint32_t seed;         // noise model for the culled bins
+    unsigned long long* hist;           // level-1 histogram of |dre| or null
+    int chunks;
+};
+template <class Ex>
+SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    uint32_t* lh = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    const int nt = ex.nthreads();
+    const size_t total = (size_t)p.Cb * p.R;
+    const size_t nquad = (total + 3) / 4;
+    const WeightRanges wr = weight_ranges(p.R, p.C);
+    if (p.hist) {
+        ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
+        ex.sync();
+    }
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t qi = start + (size_t)c * nt + tid;
+            if (qi >= nquad) break;
+            const size_t i0 = 4 * qi;
+            float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
+            const int n = load_quad(p.re, i0, total, p.vec4, a);
+            if (p.im) load_quad(p.im, i0, total, p.vec4, b);
+            float r[4], im[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = (fabsf(a[e]) < p.thr) ? model_noise(p.seed, i0 + e, p.sigma) : a[e] * p.scale;
+                im[e] = b[e] * p.scale;
+            }
+            if (p.vec4) {
+                cf4 v = {r[0], r[1], r[2], r[3]};
+                *(cf4*)(p.dre + i0) = v;
+                if (p.im) { cf4 vi = {im[0], im[1], im[2], im[3]}; *(cf4*)(p.dim + i0) = vi; }
+            } else {
+                for (int e = 0; e < n; ++e) { p.dre[i0 + e] = r[e]; if (p.im) p.dim[i0 + e] = im[e]; }
+            }
+            if (p.hist) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < n) ex.lds_atomic_add(&lh[(f2u(r[e]) & 0x7fffffffu) >> 20], weight_at(wr, i0 + e));
             }
         }
     });

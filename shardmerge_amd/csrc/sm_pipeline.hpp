@@ -46,6 +46,7 @@ SM_FFT_KERNEL_TAG(KF2, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>()>(ex, p)), 
 SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)), 1, 4)
 SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)), i1_bins<P>(), 4)
 SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
+SM_FFT_KERNEL_TAG(KF2S, F2SParams, "f2s_cols_fwd1", (k_f2s<P, f2s_groups<P>()>(ex, p)), f2s_groups<P>(), 4)
 
 // lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
 // and the 3/5/7 * 2^k hidden and MLP sizes of other common models: a run-time planned length
@@ -133,6 +134,8 @@ SM_KERNEL_TAG(KPack, PackParams, "pack_planes", k_pack(ex, p))
 SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
 SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
 SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
+SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
+SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
 
 // ---- FFT planner ---------------------------------------------------------------
 struct HostPlan {
@@ -202,11 +205,14 @@ class Pipeline {
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
+    bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
+    float noise_sigma = 1.2e-7f;      // rounding-noise model for their culled bins (k_spec_rescale)
 
     explicit Pipeline(int device) : be(device) {}
     ~Pipeline() {
         for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
-        for (Buffer* b : {&cand_, &t1_, &planes_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        for (Buffer* b : {&cand_, &t1_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        for (Buffer& b : pool_) if (b.p) be.free(b.p);
         if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
     }
@@ -260,8 +266,9 @@ class Pipeline {
         return SMHIP_OK;
     }
     size_t workspace_bytes() const {
-        size_t t = cand_.cap + t1_.cap + planes_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
+        size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
         for (const Buffer& b : inter_) t += b.cap;
+        for (const Buffer& b : pool_) t += b.cap;
         return t;
     }
 
@@ -298,7 +305,8 @@ class Pipeline {
         const Geo g = geo(R, C, full);
         int rc;
         if ((rc = ensure(t1_, round_up((size_t)R, 4) * g.pitch4 * sizeof(cf4)))) return rc;
-        if ((rc = ensure(planes_, 4 * g.plane_floats * sizeof(float)))) return rc;
+        for (int i = 0; i < 4; ++i)
+            if ((rc = ensure(pool_[pidx_[i]], g.plane_floats * sizeof(float)))) return rc;
         {   // candidate lists of the selection passes: ~1 % of the data is expected
             const size_t ck = std::max<size_t>(1 << 16, g.plane_floats / 4), cp = std::max<size_t>(1 << 15, g.plane_floats / 16);
             if ((rc = ensure(cand_, ck * 4 + cp * 16))) return rc;
@@ -340,8 +348,20 @@ class Pipeline {
     }
     double* d_norm2() { return (double*)((char*)small_.p + OFF_NORM2); }
     double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
-    float* plane(const Geo& g, int i) { return (float*)planes_.p + (size_t)i * g.plane_floats; }
+    // The four working planes come from a pool of equally sized buffers: a pair merge whose
+    // result stays in the spectral domain (K >= 3) keeps its Re R / Im a planes as they are - the
+    // planes are detached from the working set and fresh ones take their place.
+    float* plane(const Geo&, int i) { return (float*)pool_[pidx_[i]].p; }
     enum { P_REA = 0, P_IMA = 1, P_REB = 2, P_RER = 3 };
+    int pool_acquire(size_t bytes) {
+        int id = -1;
+        for (size_t q = 0; q < pool_.size(); ++q) if (!pool_busy_[q]) { id = (int)q; break; }
+        if (id < 0) { pool_.emplace_back(); pool_busy_.push_back(0); id = (int)pool_.size() - 1; }
+        if (ensure(pool_[id], bytes)) return -1;
+        pool_busy_[id] = 1;
+        return id;
+    }
+    void pool_release(int id) { if (id >= 0) pool_busy_[id] = 0; }
 
     static bool is_static_plan(const FftPlanDev& pl) {
         bool found = false;
@@ -398,6 +418,7 @@ class Pipeline {
         if (rc) return rc;
         p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = g.ilv;
         p.nb = std::max(1, 256 / p.plan.T);
+        p.row_stride = (size_t)g.C;
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
@@ -409,6 +430,77 @@ class Pipeline {
         grid_out = grid;
         return SMHIP_OK;
     }
+    // ---- one signal (rounds >= 2: the pair's other input stayed spectral) ---------------------
+    static size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+    // rows (2m, 2m+1) of ONE signal as the two operands of the two-for-one row transform:
+    // T1[m][k] = (spectrum of row 2m, spectrum of row 2m+1).  R must be even.
+    int run_f1_rowpairs(const Geo& g, const SigDesc& sig) {
+        F1Params p;
+        int rc = get_plan(g.C, p.plan);
+        if (rc) return rc;
+        SigDesc a = sig, b = sig;
+        b.x = (const char*)sig.x + (size_t)g.C * dt_size(sig.dtype);
+        if (sig.base) b.base = (const char*)sig.base + (size_t)g.C * dt_size(sig.dtype);
+        p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = 1;
+        p.nb = std::max(1, 256 / p.plan.T);
+        p.row_stride = (size_t)2 * g.C;
+        p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        p.t1 = (cf4*)t1_.p;
+        p.partials = d_part();
+        const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8);
+        if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
+        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+        return SMHIP_OK;
+    }
+    int run_f2s(const Geo& g, bool role_a, float scale, bool hist) {
+        F2SParams p;
+        int rc = get_plan(g.R, p.plan);
+        if (rc) return rc;
+        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
+        p.role_a = role_a ? 1 : 0; p.scale = scale;
+        p.re = plane(g, role_a ? P_REA : P_REB); p.im = plane(g, P_IMA);
+        p.hist = hist ? d_hist() : nullptr;
+        const bool st = is_static_plan(p.plan);
+        const int G = st ? (f2_nsig_for(p.plan.T) == 2 ? 2 * f2_bins_for(p.plan.T) : 1) : 1;
+        const int xg = G >= 8 ? 1 : 8 / G;
+        const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
+        launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
+        return SMHIP_OK;
+    }
+    // sum over the full spectrum of |R_culled|^2 of the planes (re, im) -> (sum_re, sum_im), one sync
+    void run_spec_norm(const Geo& g, const float* re, const float* im, const float* thr, double& sre, double& sim) {
+        const size_t total = (size_t)g.Cb * g.R;
+        SpecNormParams q;
+        q.re = re; q.im = im; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.thr = thr;
+        q.chunks = pick_chunks((total + 3) / 4, 256, 8, 8);
+        int grid = stream_grid((total + 3) / 4, 256, q.chunks);
+        while ((size_t)grid * 2 > PART_DOUBLES) { q.chunks *= 2; grid = stream_grid((total + 3) / 4, 256, q.chunks); }
+        q.partials = d_part();
+        be.template launch<KSpecNorm>(grid, 256, LDS_SCRATCH_FLOATS * 4, q, stream);
+        SumPartialsParams sp;
+        sp.partials = d_part(); sp.nparts = grid; sp.out = mail_->norm2;
+        be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        // the cull threshold travels with the intermediate as a VALUE (d_thr(1) is reused by the next pair)
+        PublishParams pp;
+        pp.flags = d_flags(); pp.thr = d_thr(0); pp.consts = d_consts(); pp.mail = mail_; pp.zero_flags = nullptr;
+        be.template launch<KPublish>(1, 64, LDS_SCRATCH_FLOATS * 4, pp, stream);
+        be.sync(stream);
+        sre = mail_->norm2[0]; sim = mail_->norm2[1];
+    }
+    void run_spec_rescale(const Geo& g, const float* re, const float* im, float thr, float scale, bool role_a, bool hist) {
+        const size_t total = (size_t)g.Cb * g.R;
+        SpecRescaleParams q;
+        q.re = re; q.im = role_a ? im : nullptr;
+        q.dre = plane(g, role_a ? P_REA : P_REB); q.dim = plane(g, P_IMA);
+        q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g);
+        q.thr = thr; q.scale = scale; q.sigma = noise_sigma; q.seed = ++noise_seed_;
+        q.hist = hist ? d_hist() : nullptr;
+        q.chunks = pick_chunks((total + 3) / 4, 256, 8, 8);
+        be.template launch<KSpecRescale>(stream_grid((total + 3) / 4, 256, q.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, q, stream);
+    }
+
     void read_norms(int grid, double& na, double& nb) {
         SumPartialsParams sp;
         sp.partials = d_part(); sp.nparts = grid; sp.out = mail_->norm2;     // host-mapped: no copy, one sync
@@ -546,12 +638,12 @@ class Pipeline {
     // norm_grid (optional): the row pass also leaves the sum of squares of what it stores in
     // d_part(), *norm_grid work-groups of it (read_norms() finishes the reduction)
     int run_inverse(const Geo& g, const float* reR, const float* imA, const float* cull_thr, const PairOut& o,
-                    int* norm_grid = nullptr) {
+                    int* norm_grid = nullptr, float cull_val = 0.f) {
         I1Params a;
         int rc = get_plan(g.R, a.plan);
         if (rc) return rc;
         const int Cb = g.C / 2 + 1;
-        a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.R = g.R; a.Cb = Cb;
+        a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.cull_val = cull_val; a.R = g.R; a.Cb = Cb;
         if (g.R == 1) {
             a.s = 1; a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
             be.template launch<KI1R1>(std::max(1, std::min(64, (Cb + 255) / 256)), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
@@ -833,10 +925,35 @@ class Pipeline {
     }
 
     struct Slot {           // one entry of the reference's layer_stack
-        SigDesc sig;        // where its values live
+        SigDesc sig;        // where its values live (spatial)
         double weight;
         double norm;        // ||.||_2 if known, else < 0
+        // spectral intermediate (result of an earlier SLERP pair merge, K >= 3): the pair's Re R and
+        // Im a planes, detached from the working set; the cull is still to be applied (thr)
+        bool spectral = false;
+        int re_id = -1, im_id = -1;     // pool buffers
+        float thr = 0.f;                // cull threshold (0: none)
+        double spec_scale = 1.0;        // 1 / sqrt(sum |R_culled|^2 / n): brings the spectrum to unit spatial norm
+        double post = 1.0;              // spatial values = post * ifft(R)   (target_norm)
     };
+    // spectral -> spatial fp32 (the branches that need spatial inputs: add, Arithmetic-FFT, early-out)
+    int materialise(const Geo& g, Slot& s, std::vector<char>& inter_busy) {
+        if (!s.spectral) return SMHIP_OK;
+        const size_t n = (size_t)g.R * g.C;
+        int id = -1;
+        for (size_t q = 0; q < inter_.size(); ++q) if (!inter_busy[q]) { id = (int)q; break; }
+        if (id < 0) { inter_.emplace_back(); inter_busy.push_back(0); id = (int)inter_.size() - 1; }
+        int rc = ensure(inter_[id], n * sizeof(float));
+        if (rc) return rc;
+        inter_busy[id] = 1;
+        PairOut po;
+        po.out = inter_[id].p; po.out_mode = OUT_F32; po.post = (float)s.post;
+        if ((rc = run_inverse(g, (const float*)pool_[s.re_id].p, (const float*)pool_[s.im_id].p, nullptr, po, nullptr, s.thr))) return rc;
+        pool_release(s.re_id); pool_release(s.im_id);
+        s.spectral = false; s.re_id = s.im_id = -1;
+        s.sig = SigDesc{inter_[id].p, nullptr, DT_F32, 1.f};
+        return SMHIP_OK;
+    }
 
     // all delta norms in one pass (16-bit inputs, at most two distinct bases, aligned, n % 8 == 0);
     // false: not applicable, the caller takes the pairwise path
@@ -955,6 +1072,12 @@ class Pipeline {
         double cull_pct = d.cull_start_pct;
 
         std::vector<char> inter_busy(inter_.size(), 0);
+        for (size_t q = 0; q < pool_.size(); ++q) {          // planes an aborted call left detached
+            bool working = false;
+            for (int i = 0; i < 4; ++i) working = working || pidx_[i] == (int)q;
+            pool_busy_[q] = working ? 1 : 0;
+        }
+        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2;
         int step = 0;
         int deferred_step = -1;
         bool deferred_cut = false, deferred_cull = false;
@@ -987,8 +1110,11 @@ class Pipeline {
                 // destination: final output when this is the last merge, else an fp32 intermediate
                 PairOut po;
                 float* inter = nullptr;
+                const bool slerp_proper = !(ca < 1e-6) && !(cb < 1e-6 || ratio < 0.1) && !(nb < 1e-4 || na < 1e-4);
                 if (last_round) {
                     po = fin;
+                } else if (slerp_proper && spectral_ok) {
+                    // the result stays in the spectral domain: no fp32 buffer
                 } else {
                     int id = -1;
                     for (size_t q = 0; q < inter_.size(); ++q) if (!inter_busy[q]) { id = (int)q; break; }
@@ -1004,6 +1130,14 @@ class Pipeline {
                 smhip_blend_info info;
                 memset(&info, 0, sizeof info);
                 double out_norm = -1;
+                Slot spec_slot;
+                if (!slerp_proper && (A.spectral || Bs.spectral)) {
+                    // these branches work on spatial values
+                    if ((rc = materialise(g, stack[x], inter_busy))) return rc;
+                    if ((rc = materialise(g, stack[y], inter_busy))) return rc;
+                    A = swapped ? stack[y] : stack[x]; Bs = swapped ? stack[x] : stack[y];
+                }
+                bool out_spectral = false;
                 if (ca < 1e-6) {
                     branch = SMHIP_BRANCH_ADD;                       // merged = a + b
                     int grid;
@@ -1034,17 +1168,59 @@ class Pipeline {
                         else run_combine(A.sig, none, sc, 0.f, n, inter, nullptr, false);
                         branch = SMHIP_BRANCH_EARLY_V0;
                     } else {
-                        if (!(f1_ready && d.k == 2)) {
-                            int grid;
-                            if ((rc = run_f1(g, stack[x].sig, stack[y].sig, grid))) return rc;
+                        const bool any_spec = stack[x].spectral || stack[y].spectral;
+                        if (!any_spec) {
+                            if (!(f1_ready && d.k == 2)) {
+                                int grid;
+                                if ((rc = run_f1(g, stack[x].sig, stack[y].sig, grid))) return rc;
+                            }
+                            f1_ready = false;
+                            // T1 slot 0 holds stack[x], slot 1 holds stack[y]; role "a" is the larger norm
+                            const float s0 = (float)(1.0 / (double)(float)stack[x].norm);
+                            const float s1 = (float)(1.0 / (double)(float)stack[y].norm);
+                            if ((rc = run_f2(g, s0, s1, swapped ? 1 : 0, d.cutoff_pct > 0))) return rc;
+                        } else {
+                            // at least one input stayed in the spectral domain: bring each input's
+                            // planes in on its own (the level-1 histogram accumulates over both)
+                            f1_ready = false;
+                            for (int side = 0; side < 2; ++side) {
+                                const Slot& in = side == 0 ? stack[x] : stack[y];
+                                const bool role_a = (side == 0) != swapped;
+                                if (in.spectral) {
+                                    run_spec_rescale(g, (const float*)pool_[in.re_id].p, (const float*)pool_[in.im_id].p, in.thr,
+                                                     (float)in.spec_scale, role_a, d.cutoff_pct > 0);
+                                } else {
+                                    if ((rc = run_f1_rowpairs(g, in.sig))) return rc;
+                                    if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0))) return rc;
+                                }
+                            }
                         }
-                        f1_ready = false;
-                        // T1 slot 0 holds stack[x], slot 1 holds stack[y]; role "a" is the larger norm
-                        const float s0 = (float)(1.0 / (double)(float)stack[x].norm);
-                        const float s1 = (float)(1.0 / (double)(float)stack[y].norm);
-                        if ((rc = run_f2(g, s0, s1, swapped ? 1 : 0, d.cutoff_pct > 0))) return rc;
                         bool have_cull;
                         spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull);
+                        for (int side = 0; side < 2; ++side) {          // consumed spectral inputs give their planes back
+                            Slot& in = side == 0 ? stack[x] : stack[y];
+                            if (in.spectral) { pool_release(in.re_id); pool_release(in.im_id); in.re_id = in.im_id = -1; }
+                        }
+                        if (!last_round && spectral_ok) {
+                            // the result stays spectral: its norm by Parseval, its planes detached
+                            double sre, sim;
+                            run_spec_norm(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, sre, sim);
+                            read_blend_info(&info, d.cutoff_pct > 0, have_cull, true, /*published=*/true);
+                            const double ssum = (sre + sim) / (double)n;
+                            out_spectral = true;
+                            spec_slot = Slot();
+                            spec_slot.spectral = true;
+                            spec_slot.re_id = pidx_[P_RER]; spec_slot.im_id = pidx_[P_IMA];
+                            spec_slot.thr = have_cull ? mail_->thr[1] : 0.f;
+                            spec_slot.spec_scale = ssum > 0 ? 1.0 / std::sqrt(ssum) : 1.0;
+                            spec_slot.post = target_norm;
+                            spec_slot.norm = target_norm * std::sqrt(ssum);
+                            spec_slot.sig = SigDesc{nullptr, nullptr, DT_F32, 1.f};
+                            const int r1 = pool_acquire(g.plane_floats * sizeof(float));
+                            const int r2 = pool_acquire(g.plane_floats * sizeof(float));
+                            if (r1 < 0 || r2 < 0) return SMHIP_ERR_NOMEM;
+                            pidx_[P_RER] = r1; pidx_[P_IMA] = r2;
+                        } else {
                         PairOut ps = po;
                         ps.post = (float)target_norm;                       // merged * target_norm (fast_fourier.py:243)
                         float* dtmp = nullptr;
@@ -1060,6 +1236,7 @@ class Pipeline {
                         } else {
                             read_blend_info(&info, d.cutoff_pct > 0, have_cull, true);
                         }
+                        }
                     }
                 }
                 if (branch == SMHIP_BRANCH_SLERP) { info.t = a_w / (a_w + b_w); info.cull_pct = cull_pct; }
@@ -1067,7 +1244,10 @@ class Pipeline {
                 ++step;
                 for (size_t q = 0; q < inter_.size(); ++q)     // inputs that were intermediates are dead now
                     if (inter_[q].p && (inter_[q].p == stack[x].sig.x || inter_[q].p == stack[y].sig.x)) inter_busy[q] = 0;
-                if (!last_round) {
+                if (!last_round && out_spectral) {
+                    spec_slot.weight = (a_w + b_w) / 2.0;
+                    next.push_back(spec_slot);
+                } else if (!last_round) {
                     // the next round needs ||merged|| (fast_fourier.py:209-210)
                     SigDesc ms{inter, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
                     int grid = inv_grid;             // the inverse row pass summed the squares it stored
@@ -1200,7 +1380,11 @@ class Pipeline {
     // profiling table lives in the backend
   private:
     std::map<int, HostPlan> plans_;
-    Buffer t1_, planes_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
+    Buffer t1_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
+    std::vector<Buffer> pool_ = std::vector<Buffer>(4);
+    std::vector<char> pool_busy_ = std::vector<char>(4, 1);
+    int pidx_[4] = {0, 1, 2, 3};
+    uint32_t noise_seed_ = 0;
     uint32_t cap_keys_ = 0, cap_pairs_ = 0;
     bool overflow_seen_ = false;
     bool flags_clean_ = false;

@@ -197,6 +197,7 @@ def test_mixed_input_dtypes_are_promoted_not_demoted(engine):
         ref = so.merge_layer(f_list, [base32, base32], so.ALPHAS[:2], base32)
         out, rep = engine.merge_layer(f_list, [base32, base32], so.ALPHAS[:2], base32)
         assert rep.branches == ["slerp"]
+        out = out.cpu()
         total, resid = pc.spectral_residual(out.float(), ref.float())
         assert resid < 1e-4 and (out.view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 0.02
 
@@ -269,3 +270,41 @@ def test_nan_inf_policy_in_the_inverse_row_pass(engine):
         engine.merge_layer(fts, [base, base], [0.3, 0.5], bo, layer_name="model.layers.1.mlp")
     out2, _ = engine.merge_layer(fts, [base, base], [0.3, 0.5], base)     # the context stays usable
     assert torch.equal(out2.cpu(), clean)
+
+
+@pytest.mark.parametrize("cid", ["layer_k3", "layer_k4"])
+def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(engine, golden, cid):
+    """K >= 3: an intermediate stays in the spectral domain (no inverse + forward transform between
+    rounds; the rounding noise the reference's round trip leaves in the culled bins is modelled).
+    Both paths must sit within the reference's own reproducibility floor of each other, and the
+    spectral one must really skip the transforms."""
+    case = [c for c in gi.LAYER_CASES if c["id"] == cid][0]
+    tensors, use, cfg, lname = pc.models_in_window(case)
+    fts = [tensors[m["model"]] for m in use]
+    bases = [tensors[m["base"]] for m in use]
+    alphas = [m["alpha"] for m in use]
+    bo = tensors[cfg["output_base_model"]]
+    k = len(fts)
+
+    def run(spectral):
+        engine.ctx.debug_option("spectral_intermediates", 1 if spectral else 0)
+        engine.ctx.profile(True)
+        engine.ctx.profile_reset()
+        try:
+            out, rep, delta = engine.merge_layer(fts, bases, alphas, bo, want_delta=True)
+            return out.cpu(), rep, delta.cpu(), engine.ctx.profile_table()
+        finally:
+            engine.ctx.profile(False)
+            engine.ctx.debug_option("spectral_intermediates", 1)
+
+    out_s, rep_s, delta_s, tab_s = run(True)
+    out_m, rep_m, delta_m, tab_m = run(False)
+    n_pairs = k - 1
+    assert tab_m["i2_rows_inv"][0] == n_pairs and "spec_rescale" not in tab_m
+    assert tab_s["i2_rows_inv"][0] == 1 and tab_s["i1_cols_inv"][0] == 1          # only the final inverse
+    assert tab_s["spec_norm"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
+    assert tab_s["f1_rows_fwd"][0] == (k + 1) // 2                                 # K = 4: two pairs of raw deltas, then none
+    assert rep_s.branches == rep_m.branches
+    floor = golden.manifest["layer_self_floor"][cid]
+    from oracle import spectral_oracle as so
+    assert so.rel_err(out_s.float(), out_m.float()) <= 2.0 * floor
