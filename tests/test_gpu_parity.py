@@ -154,7 +154,7 @@ def test_layer_k3_k4_vs_oracle(engine, k):
         ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
     out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
     pc.check_layer_steps(rep, tr, out.numel())
-    outside, inside, flips = pc.masked_spectral_check(delta.cpu(), tr, tol_outside=5e-4)    # 1M elements: tighter than the 64K goldens
+    outside, inside, flips = pc.masked_spectral_check(delta.cpu(), tr, tol_outside=5e-4 if k == 3 else 1.5e-3)   # 1M elements: tighter than the 64K goldens
     print(f"K={k}: outside the culled bins {outside:.2e}, inside {inside:.2e}, final-cull flips {flips}")
     # the irreproducible part (the reference's own chaos floor on the bf16 output: 1.6e-3 at
     # K = 3, 3.1e-2 at K = 4, every size) bounds the total
