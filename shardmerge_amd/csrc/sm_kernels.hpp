@@ -207,6 +207,11 @@ struct F1Params {
     int vec;               // 1: C % 8 == 0 and 16-byte aligned inputs
     cf4* t1;               // the column pass reads ilv*16 contiguous bytes per (row group, bin)
     double* partials;      // [grid][2]: sum a^2, sum b^2 of this work-group
+    // k_f1q only (radix-4 column step folded into the row pass):
+    int R2;                // transforms per slab: work-group w handles "rows" w + g*R2, g = 0..3
+    int rowpair;           // 1: row-pair mode (a = row 2w, b = row 2w+1 of one tensor; row_stride = 2C)
+    int Rcol;              // column length R (the folded twiddles are W_R)
+    const cf2* twR;        // exp(-2 pi i j / R), j < R
 };
 
 template <class P> constexpr bool f1_full_batch() {
@@ -454,6 +459,224 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
 }
 
 // =====================================================================
+// F1Q: forward row pass with the first radix-4 step of the COLUMN transform folded in.
+//
+// A long column (28672 = 7 * 2^12 rows of a Llama-3-70B MLP tensor) does not fit the engine's
+// efficient regime: one 1024-thread work-group per signal, lock-step, 8-byte strided reads -
+// 1.8 TB/s.  Split R = 4 * R2 (decimation in time, n = n1 * R2 + n2, k = k1 + 4 * k2):
+//     X[k1 + 4 k2] = sum_{n2} W_R2^{n2 k2} * ( W_R^{n2 k1} * sum_{n1} x[n1 R2 + n2] W_4^{n1 k1} )
+// The inner radix-4 butterfly over rows n2, n2 + R2, n2 + 2 R2, n2 + 3 R2 and its twiddle are
+// element-wise in the bin index, so the work-group that has just transformed those four ROWS
+// does them (three twiddles per work-group), and the column pass runs plain R2-point
+// transforms (7168 points: 256 threads, two signals per work-group) on 4 * Cb "virtual"
+// columns (k1, bin).  The spectrum planes then hold each bin column in the order
+// [k1][k2] instead of k - every consumer between the transforms is order-blind inside a
+// column, and the inverse column pass reads that order back (k_i1, FOLD).
+// T1 here: element (n2, k1, bin) at ((n2 / ilv) * 4 * pitch4 + k1 * pitch4 + bin) * ilv + n2 % ilv.
+// =====================================================================
+#ifndef SM_F1Q_QB
+#define SM_F1Q_QB 1          // 16-byte loads per operand in flight per batch (register budget: 128)
+#endif
+#ifndef SM_F1Q_PACK
+#define SM_F1Q_PACK true
+#endif
+template <class P> constexpr bool f1q_eligible() {
+    if constexpr (P::is_static) return 4 * P::T <= 1024 && (P::N / P::T) % 2 == 0 && P::N % 8 == 0; else return false;
+}
+
+template <class P, class Ex>
+SM_HD void k_f1q(Ex& ex, const F1Params& p) {
+    if constexpr (!f1q_eligible<P>()) { return; } else {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
+    const FftPlanDev& pl = p.plan;
+    constexpr int T = P::T, C = P::N, LF = P::lds_floats;
+    constexpr int E2 = C / T / 2;                  // bins k = t + u*T, u < E2, plus the Nyquist bin (t = 0, u = E2)
+    constexpr int NJ = (E2 + 3) / 4;               // main bins per thread: u = 4*jj + g
+    static_assert(NJ * 8 + 4 <= EREG, "register slots");
+    const int bid = (p.ilv > 1) ? xcd_remap(ex.bid(), p.ilv) : ex.bid();
+    const int pbid = ex.bid();
+    const int unit = bid;                           // n2 (or the row-pair index m2)
+    const bool live = unit < p.R2;
+
+    ex.each(st, [&](int tid, FftState& s) {
+        const int g = tid / T, t = tid % T;
+        const int row = unit + g * p.R2;
+        const bool valid = live;
+        double sa = 0.0, sb = 0.0;
+        constexpr int NQ = EMAX / 8;
+        // (offsets are recomputed where they are used: every register counts at 128 per thread)
+        const size_t rowoff = (size_t)row * p.row_stride;
+        auto okq = [&](int q) { return valid && 8 * (t + q * T) < C; };
+        auto offq = [&](int q) { return okq(q) ? rowoff + 8 * (t + q * T) : (size_t)0; };
+        if (p.a.dtype != DT_F32 && p.b.dtype != DT_F32) {
+            // 16-bit inputs: two batches of 16-byte loads (the 128-VGPR budget of a 1024-thread
+            // work-group), issued back to back, clamped instead of branched around
+            u32x4 ra[NQ], rab[NQ], rb[NQ], rbb[NQ];     // (only one batch of them is live at a time)
+            const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
+            const u32x4* pa = (const u32x4*)p.a.x;
+            const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
+            const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
+            const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
+            constexpr int QB = SM_F1Q_QB;
+            static_for<0, NQ / QB>([&](auto h_c) {
+                constexpr int Q0 = decltype(h_c)::value * QB, Q1 = Q0 + QB;
+#pragma unroll
+                for (int q = Q0; q < Q1; ++q) ra[q] = pa[offq(q) / 8];
+#pragma unroll
+                for (int q = Q0; q < Q1; ++q) rab[q] = pab[offq(q) / 8];
+#pragma unroll
+                for (int q = Q0; q < Q1; ++q) rb[q] = pb[offq(q) / 8];
+#pragma unroll
+                for (int q = Q0; q < Q1; ++q) rbb[q] = pbb[offq(q) / 8];
+#pragma unroll
+                for (int q = Q0; q < Q1; ++q) {
+                    float va[8], vb[8], ba[8], bb[8];
+                    decode16x8(ra[q], p.a.dtype, va);
+                    decode16x8(rab[q], p.a.dtype, ba);
+                    decode16x8(rb[q], p.b.dtype, vb);
+                    decode16x8(rbb[q], p.b.dtype, bb);
+                    float qa = 0.f, qb = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float xa = (va[c] - (has_ab ? ba[c] : 0.f)) * p.a.prescale;
+                        float xb = has_b ? (vb[c] - (has_bb ? bb[c] : 0.f)) * p.b.prescale : 0.f;
+                        if (!okq(q)) { xa = 0.f; xb = 0.f; }
+                        s.xr[q * 8 + c] = xa; s.xi[q * 8 + c] = xb;
+                        qa += xa * xa; qb += xb * xb;
+                    }
+                    sa += qa; sb += qb;
+                }
+            });
+        } else {
+            auto load_signal = [&](const SigDesc& sg, float* dst, double& ss) {
+                if (!sg.x) {
+#pragma unroll
+                    for (int i = 0; i < 8 * NQ; ++i) dst[i] = 0.f;
+                    return;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    float v[8];
+                    load_sig8(sg, offq(q), v);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float x = okq(q) ? v[c] : 0.f;
+                        dst[q * 8 + c] = x;
+                        ps += x * x;
+                    }
+                    ss += ps;
+                }
+            };
+            load_signal(p.a, s.xr, sa);
+            load_signal(p.b, s.xi, sb);
+        }
+        s.red[0] = sa; s.red[1] = sb;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) {
+        p.partials[2 * (size_t)pbid] = tot[0];
+        p.partials[2 * (size_t)pbid + 1] = tot[1];
+    });
+
+    wg_fft<P, SM_F1Q_PACK>(ex, st, pl, lds,
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // natural scatter
+            const int g = tid / T, t = tid % T;
+            float* l = lds + g * LF;
+            const float* x = comp_of<comp>(s);
+#pragma unroll
+            for (int q = 0; q < EMAX / 8; ++q) {
+                const int n0 = 8 * (t + q * T);
+                if (n0 < C) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) l[lpad(n0 + c)] = x[q * 8 + c];
+                }
+            }
+        },
+        [&](int tid, FftState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;
+            // every thread takes a quarter of the bins, of ALL FOUR rows: slot (jj*4 + g')*2 + {0, 1}
+            const int g = tid / T, t = tid % T;
+            float* o = comp_of<comp>(s);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int u = 4 * jj + g;
+                if (u < E2) {
+                    const int k = t + u * T;
+                    const int k2 = (k == 0) ? 0 : C - k;
+#pragma unroll
+                    for (int gp = 0; gp < 4; ++gp) {
+                        const float* l = lds + gp * LF;
+                        const float v1 = l[lpad(k)], v2 = l[lpad(k2)];
+                        const int sl = (jj * 4 + gp) * 2;
+                        if (comp == 0) { o[sl] = 0.5f * (v1 + v2); o[sl + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
+                        else           { o[sl] = 0.5f * (v1 - v2); o[sl + 1] = 0.5f * (v1 + v2); }   // A.im, B.re
+                    }
+                }
+            }
+            if (tid == 0) {                                  // the Nyquist bin k = C/2: its own twin
+#pragma unroll
+                for (int gp = 0; gp < 4; ++gp) o[NJ * 8 + gp] = lds[gp * LF + lpad(C / 2)];
+            }
+        });
+
+#ifndef SM_DBG_NOSTORE
+    ex.each(st, [&](int tid, FftState& s) {
+        if (!live) return;
+        const int g = tid / T, t = tid % T;
+        // twiddles W_R^{n2 k1}: slot A is column element n2A, slot B n2B (they differ in row-pair mode)
+        const int n2A = p.rowpair ? 2 * unit : unit, n2B = p.rowpair ? 2 * unit + 1 : unit;
+        cf2 wA[4], wB[4];
+        wA[0].x = 1.f; wA[0].y = 0.f; wB[0] = wA[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 4; ++k1) { wA[k1] = p.twR[(size_t)n2A * k1]; wB[k1] = p.twR[(size_t)n2B * k1]; }
+        const bool has_b = p.b.x != nullptr;
+        cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * 4 * p.pitch4 * p.ilv + (unit % p.ilv);
+        const size_t slabstride = (size_t)p.pitch4 * p.ilv;
+        auto emit = [&](int k, const float* are, const float* aim, const float* bre, const float* bim) {
+            SM_SCHED_FENCE();                      // one bin's butterflies at a time (register pressure)
+            float ar[4], ai[4], br[4], bi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ar[q] = are[q]; ai[q] = aim[q]; br[q] = has_b ? bre[q] : 0.f; bi[q] = has_b ? bim[q] : 0.f; }
+            Dft<4>::run(ar, ai);
+            Dft<4>::run(br, bi);
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) {
+                if (k1) { cmul(ar[k1], ai[k1], wA[k1].x, wA[k1].y); cmul(br[k1], bi[k1], wB[k1].x, wB[k1].y); }
+                cf4 v = {ar[k1], ai[k1], br[k1], bi[k1]};
+                rowp[(size_t)k * p.ilv + k1 * slabstride] = v;
+            }
+            SM_SCHED_FENCE();
+        };
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int u = 4 * jj + g;
+            if (u < E2) {
+                float are[4], aim[4], bre[4], bim[4];
+#pragma unroll
+                for (int gp = 0; gp < 4; ++gp) {
+                    const int sl = (jj * 4 + gp) * 2;
+                    are[gp] = s.xr[sl]; bim[gp] = s.xr[sl + 1]; aim[gp] = s.xi[sl]; bre[gp] = s.xi[sl + 1];
+                }
+                emit(t + u * T, are, aim, bre, bim);
+            }
+        }
+        if (tid == 0) {
+            float are[4], aim[4] = {0.f, 0.f, 0.f, 0.f}, bre[4], bim[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gp = 0; gp < 4; ++gp) { are[gp] = s.xr[NJ * 8 + gp]; bre[gp] = s.xi[NJ * 8 + gp]; }
+            emit(C / 2, are, aim, bre, bim);
+        }
+    });
+#else
+    ex.each(st, [&](int tid, FftState& s) { float acc = 0.f; for (int q = 0; q < 36; ++q) acc += s.xr[q] + s.xi[q]; p.t1[tid].x = acc; });
+#endif
+    }
+}
+
+// =====================================================================
 // F2: forward column pass (one half-spectrum bin column of A and of B)
 // =====================================================================
 struct F2Params {
@@ -467,7 +690,17 @@ struct F2Params {
     float scale[2];        // per slot: 1/norm (or the arithmetic branch's scale)
     float* reA; float* imA; float* reB;     // planes [Cb][R]; role b writes only reB
     unsigned long long* hist;               // level-1 histogram (HIST1_BINS) or null
+    // FOLD variants (see k_f1q): R is the sub-length R2, Cb counts the 4 * slab virtual columns
+    int slab;              // virtual columns per k1 (the real T1 pitch in float4)
+    int Cb_real;           // bins per slab that exist (C/2 + 1)
+    int Rfull;             // 4 * R: a bin column of the planes
 };
+// virtual column v of a folded column pass -> plane offset of its first element, real bin (or -1)
+SM_HD int fold_bin(int v, int slab, int Cb_real, int R2, int Rfull, size_t& off) {
+    const int k1 = v / slab, k = v % slab;
+    off = (size_t)k * Rfull + (size_t)k1 * R2;
+    return k < Cb_real ? k : -1;
+}
 
 // BINS adjacent bin columns per work-group (2*BINS transforms, 2*BINS*T threads): the
 // row segment a work-group reads is BINS*16 bytes wide, so short columns get full
@@ -488,8 +721,14 @@ struct F2Params {
 SM_HD constexpr int t1_interleave_rows(int R) { return R >= SM_T1_ILV_MIN_ROWS ? SM_T1_ILV : 1; }
 SM_HD constexpr int f2_nsig_for(int T) { return (2 * T <= SM_F2_MAX_THREADS) ? 2 : 1; }
 
-template <class P, int BINS, class Ex>
+constexpr int FOLD_ILV = 2;      // rows n2, n2 + 1 interleaved in T1 on the folded path: 32-byte pieces
+template <class P> constexpr bool fold_col_plan() {          // lengths used as R2 = R / 4
+    if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 && (P::N == 2048 || P::N == 3584 || P::N == 4096 || P::N == 7168);
+    else return false;
+}
+template <class P, int BINS, bool FOLD = false, class Ex>
 SM_HD void k_f2(Ex& ex, const F2Params& p) {
+    if constexpr (FOLD && !fold_col_plan<P>()) { return; } else {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
@@ -497,7 +736,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const int T = plan_T<P>(pl), R = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
     const int ng = P::is_static ? f2_nsig_for(T) : p.nsig;              // compile-time for static plans
-    const int ilv = P::is_static ? t1_interleave_rows(R) : p.ilv;
+    const int ilv = FOLD ? FOLD_ILV : (P::is_static ? t1_interleave_rows(R) : p.ilv);
     const int bid = ex.bid();
     // 8/BINS work-groups share a 128-byte line of T1 (16 bytes per bin)
     // (one signal per work-group, T = 1024: the 16 work-groups of a line - 8 bins x 2 signals)
@@ -590,9 +829,12 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         if (k2 >= p.Cb) return;
         const bool role_a = (slot ^ p.swap) == 0;
         const float sc = p.scale[slot];
-        const uint32_t w = (uint32_t)bin_weight(k2, p.C);
-        float* dre = (role_a ? p.reA : p.reB) + (size_t)k2 * R;
-        float* dim = p.imA + (size_t)k2 * R;
+        size_t poff = (size_t)k2 * R;
+        int kreal = k2;
+        if constexpr (FOLD) { kreal = fold_bin(k2, p.slab, p.Cb_real, R, p.Rfull, poff); if (kreal < 0) return; }
+        const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
+        float* dre = (role_a ? p.reA : p.reB) + poff;
+        float* dim = p.imA + poff;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);
@@ -632,6 +874,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
             }
         });
     }
+    }
 }
 
 // bins per work-group of the column passes for a plan with T threads per transform
@@ -668,13 +911,15 @@ struct F2SParams {
     float scale;
     float* re; float* im;  // destination planes [Cb][R] (im unused when !role_a)
     unsigned long long* hist;
+    int slab, Cb_real, Rfull;   // FOLD variant: as F2Params
 };
 template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
 }
 
-template <class P, int G, class Ex>
+template <class P, int G, bool FOLD = false, class Ex>
 SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
+    if constexpr (FOLD && !fold_col_plan<P>()) { return; } else {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
@@ -734,9 +979,12 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         const int k2 = kbase + g;
         if (k2 >= p.Cb) return;
         const float sc = p.scale;
-        const uint32_t w = (uint32_t)bin_weight(k2, p.C);
-        float* dre = p.re + (size_t)k2 * R;
-        float* dim = p.im + (size_t)k2 * R;
+        size_t poff = (size_t)k2 * R;
+        int kreal = k2;
+        if constexpr (FOLD) { kreal = fold_bin(k2, p.slab, p.Cb_real, R, p.Rfull, poff); if (kreal < 0) return; }
+        const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
+        float* dre = p.re + poff;
+        float* dim = p.im + poff;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);
@@ -775,6 +1023,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
                 if (v) ex.global_atomic_add(&p.hist[h], (unsigned long long)v);
             }
         });
+    }
     }
 }
 
@@ -831,8 +1080,15 @@ struct I1Params {
     int pitchG;
 };
 
-template <class P, int S, class Ex>
+// FOLD: the planes hold each bin column in the folded order [k1][k2] (k = k1 + 4 k2, see k_f1q):
+// the loads stay contiguous (16 bytes from slab k1), the natural position is restored in the
+// first LDS scatter.
+template <class P> constexpr bool fold_full_plan() {
+    if constexpr (P::is_static) return P::N == 8192 || P::N == 14336 || P::N == 16384 || P::N == 28672; else return false;
+}
+template <class P, int S, bool FOLD = false, class Ex>
 SM_HD void k_i1(Ex& ex, const I1Params& p) {
+    if constexpr (FOLD && !fold_full_plan<P>()) { return; } else {
     typename Ex::template State<FftState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
@@ -851,7 +1107,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         const float* sim = p.imA + (size_t)k2 * R;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
-            const int k0 = 4 * (t + u * T);
+            const int k0 = 4 * (t + u * T);            // FOLD: four consecutive elements of one slab
             float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f};
             if (valid) {
                 if (k0 + 3 < R && (R & 3) == 0) {
@@ -885,7 +1141,14 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int k1 = 4 * (t + u * T) + c;
-                    if (k1 < R) l[lpad(k1)] = x[4 * u + c];
+                    if (k1 < R) {
+                        if constexpr (FOLD) {
+                            const int R2 = R / 4;                      // stored position k1 = slab * R2 + k2
+                            l[lpad((k1 / R2) + 4 * (k1 % R2))] = x[4 * u + c];
+                        } else {
+                            l[lpad(k1)] = x[4 * u + c];
+                        }
+                    }
                 }
             }
         },
@@ -930,6 +1193,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
             }
         }
     });
+    }
 }
 
 template <class Ex>
@@ -2022,12 +2286,13 @@ SM_HD uint32_t hash_u32(uint32_t x) {
 SM_HD float model_noise(uint32_t seed, size_t i, float sigma) {
     const uint32_t h1 = hash_u32((uint32_t)i * 2u + 1u + seed * 0x9e3779b9u) ^ hash_u32((uint32_t)(i >> 31) + seed);
     const uint32_t h2 = hash_u32(h1 + 0x68bc21ebu);
-    const float u1 = ((float)(h1 >> 8) + 1.0f) * (1.0f / 16777216.0f);        // (0, 1]
-    const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
     // 8 % of the reference's noise values are exact zeros (fp32 cancellation; sign(0) = 0 is its own
     // sign class there): measured 0.094 / 0.081 / 0.076 at 256^2 / 1024^2 / 4096^2
-    if ((h2 & 0xffu) < 21u) return 0.f;
-    return sigma * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+    if ((h2 >> 24) < 21u) return 0.f;
+    // sum of four uniforms (variance 1/3): Gaussian enough - only the sign and the rank of a noise
+    // value among the other noise values ever matter - and no transcendental in a streaming kernel
+    const float s4 = (float)(h1 & 0xffffu) + (float)(h1 >> 16) + (float)(h2 & 0xffffu) + (float)(hash_u32(h2) >> 16);
+    return sigma * 1.7320508f * (s4 * (1.0f / 65536.0f) - 2.0f);
 }
 
 struct SpecRescaleParams {

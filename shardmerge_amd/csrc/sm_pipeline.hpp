@@ -47,6 +47,12 @@ SM_FFT_KERNEL_TAG(KI1x1, I1Params, "i1_cols_inv", (k_i1<P, 1>(ex, p)), 1, 4)
 SM_FFT_KERNEL_TAG(KI1x2, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>()>(ex, p)), i1_bins<P>(), 4)
 SM_FFT_KERNEL_TAG(KI2, I2Params, "i2_rows_inv", k_i2<P>(ex, p), 1, 4)
 SM_FFT_KERNEL_TAG(KF2S, F2SParams, "f2s_cols_fwd1", (k_f2s<P, f2s_groups<P>()>(ex, p)), f2s_groups<P>(), 4)
+// radix-4 column step folded into the row pass (k_f1q) and its column-side companions
+SM_FFT_KERNEL_TAG(KF1Q, F1Params, "f1_rows_fwd", k_f1q<P>(ex, p), 4, 4)
+SM_FFT_KERNEL_TAG(KF2Q, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>(), true>(ex, p)), 2 * f2_bins<P>(), 4)
+SM_FFT_KERNEL_TAG(KF2SQ, F2SParams, "f2s_cols_fwd1", (k_f2s<P, f2s_groups<P>(), true>(ex, p)), f2s_groups<P>(), 4)
+SM_FFT_KERNEL_TAG(KI1x1Q, I1Params, "i1_cols_inv", (k_i1<P, 1, true>(ex, p)), 1, 4)
+SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(ex, p)), i1_bins<P>(), 4)
 
 // lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
 // and the 3/5/7 * 2^k hidden and MLP sizes of other common models: a run-time planned length
@@ -277,10 +283,25 @@ class Pipeline {
         size_t plane_floats;      // one plane, padded
         bool full;                // planes hold the full spectrum (weights 1)
         int Cw;                   // C passed to bin_weight (-1 in full mode)
+        int fold;                 // 4: radix-4 column step folded into the row pass (k_f1q), else 1
     };
-    Geo geo(int R, int C, bool full = false) const {
+    // shapes whose column pass runs folded: a long column (its own plan needs >= 512 threads per
+    // transform) over rows short enough for four of them to share a work-group
+#ifndef SM_FOLD_MIN_ROWS
+#define SM_FOLD_MIN_ROWS 14336
+#endif
+    int fold_min_rows = SM_FOLD_MIN_ROWS;
+    bool fold_shape(int R, int C) const {
+        if (R < fold_min_rows || !(R == 8192 || R == 14336 || R == 16384 || R == 28672)) return false;
+        int T; std::vector<int> rad;
+        if (!plan_shape_static(C, T, rad)) return false;
+        return 4 * T <= 1024 && (C / T) % 2 == 0 && C % 8 == 0;
+    }
+    bool fold_enabled = true;
+    Geo geo(int R, int C, bool full = false, bool allow_fold = false) const {
         Geo g;
         g.R = R; g.C = C; g.full = full;
+        g.fold = (allow_fold && fold_enabled && !full && fold_shape(R, C)) ? 4 : 1;
         g.Cb = full ? C : C / 2 + 1;
         g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
         g.pitchG = g.pitch4;           // G: row pairs x bins, float4 (two rows' float2) per entry
@@ -422,6 +443,18 @@ class Pipeline {
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
+        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr;
+        if (g.fold == 4) {
+            if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
+            FftPlanDev colp;
+            if ((rc = get_plan(g.R, colp))) return rc;
+            p.R2 = g.R / 4; p.twR = colp.tw; p.ilv = FOLD_ILV; p.nb = 4;
+            const int gridq = (int)round_up((size_t)p.R2, 8 * p.ilv);
+            if ((size_t)gridq * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+            launch_fft<KF1Q>(p.plan, gridq, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
+            grid_out = gridq;
+            return SMHIP_OK;
+        }
         const int xg = p.ilv > p.nb ? p.ilv / p.nb : 1;
         const int grid = (int)round_up((size_t)(g.R + p.nb - 1) / p.nb, 8 * xg);
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
@@ -447,6 +480,16 @@ class Pipeline {
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
+        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr;
+        if (g.fold == 4) {
+            if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
+            FftPlanDev colp;
+            if ((rc = get_plan(g.R, colp))) return rc;
+            p.R2 = g.R / 8; p.rowpair = 1; p.twR = colp.tw; p.ilv = 1; p.nb = 4;      // units = row pairs
+            const int gridq = (int)round_up((size_t)p.R2, 8);
+            launch_fft<KF1Q>(p.plan, gridq, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
+            return SMHIP_OK;
+        }
         const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8);
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
@@ -455,9 +498,12 @@ class Pipeline {
     }
     int run_f2s(const Geo& g, bool role_a, float scale, bool hist) {
         F2SParams p;
-        int rc = get_plan(g.R, p.plan);
+        const int Rt = g.R / g.fold;                 // transform length (R2 on the folded path)
+        int rc = get_plan(Rt, p.plan);
         if (rc) return rc;
-        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
+        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4 * g.fold; p.R = Rt; p.C = g.C;
+        p.Cb = g.fold == 4 ? 4 * g.pitch4 : g.C / 2 + 1;
+        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R;
         p.role_a = role_a ? 1 : 0; p.scale = scale;
         p.re = plane(g, role_a ? P_REA : P_REB); p.im = plane(g, P_IMA);
         p.hist = hist ? d_hist() : nullptr;
@@ -466,7 +512,8 @@ class Pipeline {
         const int xg = G >= 8 ? 1 : 8 / G;
         const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
-        launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
+        if (g.fold == 4) launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p);
+        else launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
         return SMHIP_OK;
     }
     // sum over the full spectrum of |R_culled|^2 of the planes (re, im) -> (sum_re, sum_im), one sync
@@ -514,11 +561,26 @@ class Pipeline {
         int rc = get_plan(g.R, p.plan);
         if (rc) return rc;
         if (g.R == 1) {
+            p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = 1;
             p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = 1; p.R = 1; p.C = g.C; p.Cb = g.C / 2 + 1; p.nsig = 2;
             p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
             p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
             p.hist = hist ? d_hist() : nullptr;
             be.template launch<KF2R1>(std::max(1, std::min(64, (p.Cb + 255) / 256)), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, p, stream);
+            return SMHIP_OK;
+        }
+        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R;
+        if (g.fold == 4) {
+            // R2-point transforms on 4 * pitch4 virtual columns (k1, bin); see k_f1q
+            if ((rc = get_plan(g.R / 4, p.plan))) return rc;
+            p.t1 = (const cf4*)t1_.p; p.pitch4 = 4 * g.pitch4; p.ilv = FOLD_ILV; p.R = g.R / 4; p.C = g.C; p.Cb = 4 * g.pitch4;
+            p.nsig = 2; p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
+            p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
+            p.hist = hist ? d_hist() : nullptr;
+            const int binsq = f2_bins_host(p.plan);
+            const int gridq = (int)round_up((size_t)(p.Cb + binsq - 1) / binsq, 64);
+            const size_t ldsq = (LDS_SCRATCH_FLOATS + (size_t)2 * binsq * p.plan.lds_floats + HIST1_BINS) * 4;
+            launch_fft<KF2Q>(p.plan, gridq, 2 * binsq * p.plan.T, ldsq, p);
             return SMHIP_OK;
         }
         p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = g.ilv; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1;
@@ -652,7 +714,10 @@ class Pipeline {
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
         const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
-        if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
+        if (g.fold == 4) {
+            if (a.s >= 2) launch_fft<KI1x2Q>(a.plan, grid1, a.s * a.plan.T, lds1, a);
+            else launch_fft<KI1x1Q>(a.plan, grid1, a.plan.T, lds1, a);
+        } else if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
         else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
         }
 
@@ -756,7 +821,7 @@ class Pipeline {
     int merge_pair_slerp_once(const float* v0, const float* v1, int R, int C, double t, double bthr, double t_sum,
                               double cutoff_pct, double cull_pct, float* out, double* n0o, double* n1o, int* branch,
                               smhip_blend_info* info) {
-        const Geo g = geo(R, C);
+        const Geo g = geo(R, C, false, aligned16(v0) && aligned16(v1) && aligned16(out));
         int rc = reserve(R, C);
         if (rc) return rc;
         clear_flags();
@@ -863,7 +928,8 @@ class Pipeline {
     // ---- A10: task_arithmetic_fft2 on fp32 inputs ------------------------------------
     int pair_arith(const SigDesc& a_in, const SigDesc& b_in, int R, int C, float sa, float sb, double t, int agreement,
                    const PairOut& po, double na_hint, double nb_hint) {
-        const Geo g = geo(R, C);
+        const Geo g = geo(R, C, false, aligned16(a_in.x) && aligned16(a_in.base) && aligned16(b_in.x) && aligned16(b_in.base) &&
+                                       aligned16(po.out) && aligned16(po.base));
         int rc = reserve(R, C);
         if (rc) return rc;
         SigDesc a = a_in, b = b_in;
@@ -992,7 +1058,9 @@ class Pipeline {
         const int R = d.rows, C = d.cols;
         if (R < 1 || C < 1) return fail(SMHIP_ERR_ARG, "bad shape");
         const size_t n = (size_t)R * C;
-        const Geo g = geo(R, C);
+        bool all_aligned = aligned16(d.base_out) && aligned16(out_bf16) && aligned16(delta_out);
+        for (int i = 0; i < d.k; ++i) all_aligned = all_aligned && aligned16(d.finetune[i]) && aligned16(d.base[i]);
+        const Geo g = geo(R, C, false, all_aligned);
         int rc;
         if (!small_.p && (rc = reserve(1, 1))) return rc;
         clear_flags();

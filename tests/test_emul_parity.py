@@ -308,3 +308,38 @@ def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(en
     floor = golden.manifest["layer_self_floor"][cid]
     from oracle import spectral_oracle as so
     assert so.rel_err(out_s.float(), out_m.float()) <= 2.0 * floor
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_folded_column_pass(engine, k):
+    """Long columns (14336 / 28672 rows of the Llama-3 MLP tensors) run with the first radix-4
+    step of the COLUMN transform folded into the row pass (k_f1q) and R/4-point column
+    transforms on 4 x Cb virtual columns; the spectrum planes are then permuted inside a bin
+    column and the inverse column pass reads that order back.  Forced here at 8192 x 1024
+    (the smallest shape the path accepts) and compared with the oracle as any other layer,
+    K = 3 through the row-pair / single-signal variants."""
+    from oracle import spectral_oracle as so
+    rows, cols = 8192, 1024
+    base, fts = so.synthetic_layer(rows, cols, k, seed=77)
+    trx = so.LayerTrace()
+    with so.exact_norms():
+        refx = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=trx)
+    engine.ctx.debug_option("fold_min_rows", 8192)
+    engine.ctx.profile(True)
+    engine.ctx.profile_reset()
+    try:
+        out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+        engine.ctx.debug_option("fold_columns", 0)
+        out0, rep0, delta0 = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    finally:
+        engine.ctx.debug_option("fold_columns", 1)
+        engine.ctx.debug_option("fold_min_rows", 0)
+        engine.ctx.profile(False)
+    pc.check_layer_steps(rep, trx, out.numel())
+    if k == 2:
+        d_total, d_resid = pc.spectral_residual(delta, trx.merged_delta)
+        assert d_resid < 2e-5 and d_total < 8.0 / (rows * cols) ** 0.5
+        assert pc.spectral_residual(delta, delta0)[1] < 2e-6            # folded vs plain: the same up to tie bins
+    else:
+        pc.masked_spectral_check(delta, trx, tol_outside=1e-3)
+    assert so.rel_err(out.float(), refx.float()) < (1e-3 if k == 2 else 5e-3)

@@ -12,6 +12,10 @@ cols = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 eng = get_engine("cuda")
+import os
+for item in filter(None, os.environ.get("SMHIP_DEBUG", "").split(",")):      # e.g. SMHIP_DEBUG=fold_columns=0,spectral_intermediates=0
+    key, val = item.split("=")
+    eng.ctx.debug_option(key, int(val))
 g = torch.Generator(device="cuda").manual_seed(1)
 shape = (cols,) if rows == 1 else (rows, cols)
 base = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
