@@ -107,6 +107,10 @@ typedef struct {
     double cull_start_pct;                  /* 0.20 */
     double cutoff_pct;                      /* 0.08 */
     double t_sum;                           /* 1.0  */
+    double b;                               /* 0.1: merge_tensors_fft2_slerp's norm-ratio threshold below which
+                                               the pair is blended linearly, R = F0 + t F1 (functions.py:164,196-202);
+                                               unreachable at the default (the layer's own rule routes ratios < 0.1
+                                               to Arithmetic-FFT first, fast_fourier.py:226) */
 } smhip_layer_desc;
 
 typedef struct {
@@ -125,6 +129,14 @@ typedef struct {
  * merged delta before add-back, for parity checks. */
 int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf16, float* delta_out,
                       smhip_layer_report* report, void* stream);
+
+/* ---- N3: AdditionMerge / TaskAdditionMerge (reference shard/merge/addition.py:70-76,
+ *      shard/merge/taskaddition.py:69-79): out = sum_i (finetune_i - base), optionally keeping per
+ *      element only the deltas whose sign equals the majority sign.  All tensors: device, `dtype`,
+ *      n elements; the arithmetic is the dtype's, as torch does it on CPU (16-bit ops are fp32 ops
+ *      rounded to the dtype).  The base is NOT added back (the reference does not). ------------ */
+int smhip_addition_merge(smhip_ctx* ctx, int k, const void* const* finetunes, const void* base, int dtype, size_t n,
+                         int sign_agreement, void* out, void* stream);
 
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
  *      lists (0 = default) so that the overflow fallback can be exercised;

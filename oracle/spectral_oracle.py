@@ -358,11 +358,13 @@ def merge_layer(
     trace: Optional[LayerTrace] = None,
     layer_name: str = "layer",
     _mutation: Optional[str] = None,
+    ratio_b: float = 0.1,
 ) -> torch.Tensor:
     """The block-tensor branch of FourierMerge._merge_layer,
     reference shard/merge/fast_fourier.py:132-276 (+ base.py:117-137 for the
     deltas), with the disk cache replaced by a dict.  Inputs are the tensors the
     index would hand out for the models that pass ``use_layer_index``.
+    ``ratio_b`` is merge_tensors_fft2_slerp's ``b`` (the reference never overrides its 0.1).
 
     ``_mutation`` selects a DELIBERATELY WRONG variant ("keep_cull_pct": the cull
     fraction is not halved per round, :254; "swap_weights": weights follow the a/b
@@ -432,11 +434,15 @@ def merge_layer(
             else:
                 prop = a_w / (a_w + b_w)
                 btrace = BlendTrace() if trace is not None else None
-                merged, _, _ = merge_tensors_fft2_slerp(
-                    a, b, t=prop, t_sum=1.0, cutoff_pct=cutoff_pct, cull_pct=cull_pct, trace=btrace
+                merged, n0_, n1_ = merge_tensors_fft2_slerp(
+                    a, b, t=prop, b=ratio_b, t_sum=1.0, cutoff_pct=cutoff_pct, cull_pct=cull_pct, trace=btrace
                 )
                 merged = merged * target_norm
                 kind = "slerp"
+                if n1_ < 1e-4 or n0_ < 1e-4:
+                    kind = "early_v0"              # functions.py:184-190 (the HIP report names these)
+                elif n1_ / (n0_ + 1e-10) < ratio_b:
+                    kind = "linear"                # functions.py:196-202; only with ratio_b > 0.1 (N4)
             if trace is not None:
                 trace.branches.append(kind)
                 trace.pairs.append((x, y))

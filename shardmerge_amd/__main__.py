@@ -31,7 +31,8 @@ async def run_merge(config: MergeConfig, device: str, clean_cache: bool, **kwarg
     if distributed.world_size() > 1:
         await distributed.run_partitioned_merge(config, index_manager, device)
         return
-    merger = FourierMerge(config=config, index_manager=index_manager, **kwargs)
+    from .merge import operator_class
+    merger = operator_class(config.operator)(config=config, index_manager=index_manager, **kwargs)
     await merger.merge(device=device)
 
 

@@ -44,6 +44,7 @@ class LayerDesc(C.Structure):
         ("cull_start_pct", C.c_double),
         ("cutoff_pct", C.c_double),
         ("t_sum", C.c_double),
+        ("b", C.c_double),
     ]
 
 
@@ -93,6 +94,7 @@ class SmhipLibrary:
                                                      C.POINTER(I), C.POINTER(BlendInfo), P]
         d.smhip_task_arithmetic_fft2.argtypes = [P, P, P, I, I, D, I, P, P]
         d.smhip_merge_layer.argtypes = [P, C.POINTER(LayerDesc), P, P, C.POINTER(LayerReport), P]
+        d.smhip_addition_merge.argtypes = [P, I, C.POINTER(C.c_void_p), P, I, C.c_size_t, I, P, P]
         d.smhip_debug_option.argtypes = [P, C.c_char_p, C.c_long]
         d.smhip_profile_enable.argtypes = [P, I]
         d.smhip_profile_reset.argtypes = [P]

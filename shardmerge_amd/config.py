@@ -14,6 +14,9 @@ reference's shard/config.py:24-126, so existing config files work unchanged.
       cull_start_pct: 0.20
       t_sum: 1.0
       target_norm_offset: 1.0e-10
+      b: 0.1                    # merge_tensors_fft2_slerp's linear-blend threshold (functions.py:164)
+      operator: fourier         # fourier (default: what the reference CLI hard-wires, __main__.py:22,67)
+                                # | addition | task_addition (shard/merge/addition.py, taskaddition.py)
 """
 from __future__ import annotations
 
@@ -28,8 +31,10 @@ import yaml
 
 _REQUIRED = ("output_base_model", "finetune_merge", "output_dir")
 # the FFT operator's hyper-parameters and the values the reference hard-codes for them
-MERGE_OPTION_DEFAULTS = {"cutoff_pct": 0.08, "cull_start_pct": 0.20, "t_sum": 1.0, "target_norm_offset": 1e-10}
-MERGE_OPTION_RANGES = {"cutoff_pct": (0.0, 1.0), "cull_start_pct": (0.0, 1.0), "t_sum": (-1e6, 1e6), "target_norm_offset": (0.0, 1e6)}
+MERGE_OPTION_DEFAULTS = {"cutoff_pct": 0.08, "cull_start_pct": 0.20, "t_sum": 1.0, "target_norm_offset": 1e-10, "b": 0.1}
+MERGE_OPTION_RANGES = {"cutoff_pct": (0.0, 1.0), "cull_start_pct": (0.0, 1.0), "t_sum": (-1e6, 1e6), "target_norm_offset": (0.0, 1e6),
+                       "b": (0.0, 1e6)}
+OPERATORS = ("fourier", "addition", "task_addition")
 
 
 @dataclass
@@ -61,6 +66,7 @@ class MergeConfig:
     cache_dir: str = "cache"
     storage_dir: str = "storage"
     merge_options: Dict[str, float] = field(default_factory=dict)
+    operator: str = "fourier"
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -120,10 +126,14 @@ class MergeConfig:
         if not isinstance(raw["finetune_merge"], list):
             raise click.BadParameter("finetune_merge must be a list of model URIs")
         raw["finetune_merge"] = [MergeModel(**entry) for entry in raw["finetune_merge"]]
-        opts = raw.get("merge_options") or {}
+        opts = dict(raw.get("merge_options") or {})
+        operator = opts.pop("operator", "fourier")
+        if operator not in OPERATORS:
+            raise click.BadParameter(f"merge_options.operator must be one of {list(OPERATORS)}")
+        raw["operator"] = operator
         unknown = set(opts) - set(MERGE_OPTION_DEFAULTS)
         if not isinstance(opts, dict) or unknown:
-            raise click.BadParameter(f"merge_options: unknown keys {sorted(unknown)}; known: {sorted(MERGE_OPTION_DEFAULTS)}")
+            raise click.BadParameter(f"merge_options: unknown keys {sorted(unknown)}; known: {sorted(MERGE_OPTION_DEFAULTS) + ['operator']}")
         for key, value in opts.items():
             lo, hi = MERGE_OPTION_RANGES[key]
             if not isinstance(value, (int, float)) or isinstance(value, bool) or not (lo <= float(value) <= hi):

@@ -2591,6 +2591,132 @@ SM_HD void k_combine(Ex& ex, const CombineParams& p) {
     }
 }
 
+// =====================================================================
+// N3: AdditionMerge / TaskAdditionMerge (reference shard/merge/addition.py:70-76,
+// taskaddition.py:69-79) - sums of finetune deltas relative to output_base_model's tensor,
+// in the TENSORS' dtype as torch computes it on CPU: a 16-bit elementwise op is an fp32 op
+// rounded to the dtype, a 16-bit sum over the stacked dim accumulates in fp32 and rounds once.
+//   mode 0 (AdditionMerge):      out = 0; for each ft: out = rnd(out + rnd(ft - base))
+//   mode 1 (TaskAdditionMerge):  d_i = rnd(ft_i - base); s = sign(sum_i sign(d_i));
+//                                out = rnd(sum_i d_i * [sign(d_i) == s])
+// Neither adds the base back (the reference does not).
+// =====================================================================
+SM_HD uint16_t f_to_bf16_any(float v) {            // RNE, NaN stays NaN
+    const uint32_t u = f2u(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    return f_to_bf16(v);
+}
+SM_HD uint16_t f_to_f16_any(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const _Float16 h = (_Float16)v;                   // v_cvt_f16_f32 (RNE)
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+#else
+    const uint32_t u = f2u(v), sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (a >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);              // >= 65536: Inf (65520 rounds up below)
+    if (a < 0x33000000u) return (uint16_t)sign;                             // < 2^-25: zero
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                         // subnormal halves lose more bits
+    uint32_t half = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1u))) ++half;
+    uint32_t out = (e < -14) ? half : (((uint32_t)(e + 15) << 10) + (half - 0x400u));
+    return (uint16_t)(sign | out);
+#endif
+}
+SM_HD float round_to_dtype(float v, int dtype) {
+    if (dtype == DT_F32) return v;
+    if (dtype == DT_BF16) return bf16_to_f(f_to_bf16_any(v));
+    return f16_to_f(f_to_f16_any(v));
+}
+SM_HD float sign_of(float v) { return is_nan(v) ? v : (float)sgn(v); }      // torch.sign(NaN) = NaN
+
+constexpr int ADD_MAX_MODELS = 16;
+struct AdditionParams {
+    int k;
+    const void* ft[ADD_MAX_MODELS];
+    const void* base;
+    int dtype;
+    size_t n;
+    int mode;                   // 0: AdditionMerge, 1: TaskAdditionMerge
+    void* out;                  // dtype, [n]
+    int vec8;                   // n % 8 == 0 and 16-byte aligned pointers
+    int chunks;                 // octets per thread
+};
+template <class Ex>
+SM_HD void k_addition(Ex& ex, const AdditionParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t noct = (p.n + 7) / 8;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int q = 0; q < p.chunks; ++q) {
+            const size_t oi = start + (size_t)q * nt + tid;
+            if (oi >= noct) break;
+            const size_t i0 = 8 * oi;
+            const int cnt = p.vec8 ? 8 : (int)((p.n - i0) < 8 ? (p.n - i0) : 8);
+            float b[8], acc[8], ssum[8];
+            auto load8 = [&](const void* src, float* dst) {
+                if (p.vec8) { load_elem8(src, p.dtype, i0, dst); return; }
+                for (int e = 0; e < 8; ++e) dst[e] = e < cnt ? load_elem(src, p.dtype, i0 + e) : 0.f;
+            };
+            load8(p.base, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc[e] = 0.f; ssum[e] = 0.f; }
+            if (p.mode == 0) {
+                for (int i = 0; i < p.k; ++i) {
+                    float f[8];
+                    load8(p.ft[i], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = round_to_dtype(acc[e] + round_to_dtype(f[e] - b[e], p.dtype), p.dtype);
+                }
+            } else {
+                for (int i = 0; i < p.k; ++i) {                  // pass 1: the majority sign
+                    float f[8];
+                    load8(p.ft[i], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ssum[e] += sign_of(round_to_dtype(f[e] - b[e], p.dtype));
+                }
+                for (int i = 0; i < p.k; ++i) {                  // pass 2: masked sum (the inputs come from L2 now)
+                    float f[8];
+                    load8(p.ft[i], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = round_to_dtype(f[e] - b[e], p.dtype);
+                        const float keep = (sign_of(d) == sign_of(round_to_dtype(ssum[e], p.dtype))) ? 1.f : 0.f;
+                        acc[e] += round_to_dtype(d * keep, p.dtype);   // NaN * 0 = NaN, as in the reference
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = round_to_dtype(acc[e], p.dtype);
+            }
+            if (p.dtype == DT_F32) {
+                if (p.vec8) {
+                    cf4 w0 = {acc[0], acc[1], acc[2], acc[3]}, w1 = {acc[4], acc[5], acc[6], acc[7]};
+                    ((cf4*)p.out)[i0 / 4] = w0; ((cf4*)p.out)[i0 / 4 + 1] = w1;
+                } else {
+                    for (int e = 0; e < cnt; ++e) ((float*)p.out)[i0 + e] = acc[e];
+                }
+            } else {
+                uint16_t h[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = p.dtype == DT_BF16 ? f_to_bf16_any(acc[e]) : f_to_f16_any(acc[e]);
+                if (p.vec8) {
+                    u32x4 w;
+                    w.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); w.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                    w.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16); w.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+                    ((u32x4*)p.out)[oi] = w;
+                } else {
+                    for (int e = 0; e < cnt; ++e) ((uint16_t*)p.out)[i0 + e] = h[e];
+                }
+            }
+        }
+    });
+}
+
 // expand half-spectrum planes to the full complex spectrum (test / API helper:
 // the reference's fft_transform returns all R x C bins)
 struct ExpandParams {

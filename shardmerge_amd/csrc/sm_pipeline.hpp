@@ -140,6 +140,7 @@ SM_KERNEL_TAG(KPack, PackParams, "pack_planes", k_pack(ex, p))
 SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
 SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
 SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
+SM_KERNEL_TAG(KAddition, AdditionParams, "addition_merge", k_addition(ex, p))
 SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
 
@@ -1146,6 +1147,7 @@ class Pipeline {
             pool_busy_[q] = working ? 1 : 0;
         }
         const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2;
+        noise_seed_ = 0;                         // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
         int deferred_step = -1;
         bool deferred_cut = false, deferred_cull = false;
@@ -1178,7 +1180,9 @@ class Pipeline {
                 // destination: final output when this is the last merge, else an fp32 intermediate
                 PairOut po;
                 float* inter = nullptr;
-                const bool slerp_proper = !(ca < 1e-6) && !(cb < 1e-6 || ratio < 0.1) && !(nb < 1e-4 || na < 1e-4);
+                // merge_tensors_fft2_slerp's own ratio test (functions.py:196-202): linear blend below b
+                const bool linear = (nb / (na + 1e-10)) < d.b;
+                const bool slerp_proper = !(ca < 1e-6) && !(cb < 1e-6 || ratio < 0.1) && !(nb < 1e-4 || na < 1e-4) && !linear;
                 if (last_round) {
                     po = fin;
                 } else if (slerp_proper && spectral_ok) {
@@ -1235,6 +1239,22 @@ class Pipeline {
                         if (last_round) run_combine(A.sig, none, sc, 0.f, n, delta_out, &po, false);
                         else run_combine(A.sig, none, sc, 0.f, n, inter, nullptr, false);
                         branch = SMHIP_BRANCH_EARLY_V0;
+                    } else if (linear) {
+                        // R = Fa + t Fb on the normalised spectra, Im included; then * target_norm
+                        branch = SMHIP_BRANCH_LINEAR;
+                        int grid;
+                        if ((rc = run_f1(g, A.sig, Bs.sig, grid))) return rc;          // a in slot 0
+                        f1_ready = false;
+                        if ((rc = run_f2_linear(g, (float)(1.0 / na), (float)(1.0 / nb), (float)t))) return rc;
+                        PairOut ps = po;
+                        ps.post = (float)target_norm;
+                        float* dtmp = nullptr;
+                        if (last_round && delta_out) { ps = PairOut(); ps.out = delta_out; ps.post = (float)target_norm; dtmp = delta_out; }
+                        if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), nullptr, ps, last_round ? nullptr : &inv_grid))) return rc;
+                        if (dtmp) {
+                            SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
+                            run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
+                        }
                     } else {
                         const bool any_spec = stack[x].spectral || stack[y].spectral;
                         if (!any_spec) {
@@ -1307,7 +1327,7 @@ class Pipeline {
                         }
                     }
                 }
-                if (branch == SMHIP_BRANCH_SLERP) { info.t = a_w / (a_w + b_w); info.cull_pct = cull_pct; }
+                if (branch == SMHIP_BRANCH_SLERP || branch == SMHIP_BRANCH_LINEAR) { info.t = a_w / (a_w + b_w); info.cull_pct = cull_pct; }
                 if (step < SMHIP_MAX_PAIRS) { rp.step_branch[step] = branch; rp.step_info[step] = info; }
                 ++step;
                 for (size_t q = 0; q < inter_.size(); ++q)     // inputs that were intermediates are dead now
@@ -1348,6 +1368,19 @@ class Pipeline {
             rp.step_info[deferred_step].t = t_keep; rp.step_info[deferred_step].cull_pct = c_keep;
         }
         return rc;
+    }
+
+    // ---- N3: AdditionMerge / TaskAdditionMerge (one streaming kernel) ------------------------
+    int addition_merge(int k, const void* const* fts, const void* base, int dtype, size_t n, int mode, void* out) {
+        if (k < 1 || k > ADD_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
+        AdditionParams a;
+        a.k = k; a.base = base; a.dtype = dtype; a.n = n; a.mode = mode; a.out = out;
+        bool al = aligned16(base) && aligned16(out);
+        for (int i = 0; i < ADD_MAX_MODELS; ++i) { a.ft[i] = fts[i < k ? i : 0]; al = al && aligned16(a.ft[i]); }
+        a.vec8 = (n % 8 == 0) && al;
+        a.chunks = pick_chunks((n + 7) / 8, 256, 2, 8);
+        be.template launch<KAddition>(stream_grid((n + 7) / 8, 256, a.chunks), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        return SMHIP_OK;
     }
 
     // ---- transforms for the function-level API -----------------------------------------

@@ -176,11 +176,33 @@ class Engine:
             self.ctx.h, v0.data_ptr(), v1.data_ptr(), r, c, float(t), 1 if agreement else 0, out.data_ptr(), self._stream()))
         return out
 
+    # -- N3: AdditionMerge / TaskAdditionMerge ---------------------------------------------
+    def addition_merge(self, finetunes: Sequence[torch.Tensor], base: torch.Tensor, sign_agreement: bool = False) -> torch.Tensor:
+        """sum_i (finetune_i - base) in the tensors' dtype, optionally masked by the majority sign
+        (reference addition.py:70-76 / taskaddition.py:69-79).  The base is not added back."""
+        k = len(finetunes)
+        if k < 1 or k > _lib.MAX_MODELS:
+            raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
+        dtypes = {t.dtype for t in list(finetunes) + [base]}
+        dtype = next(iter(dtypes)) if len(dtypes) == 1 else torch.promote_types(*dtypes) if len(dtypes) == 2 else torch.float32
+        if dtype not in _DTYPE_CODE:
+            dtype = torch.float32
+        bs = self._dev(base, dtype)
+        fts = [self._dev(t, dtype) for t in finetunes]
+        for t in fts:
+            if t.shape != bs.shape:
+                raise ValueError(f"shape mismatch: {tuple(t.shape)} vs {tuple(bs.shape)}")
+        ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in fts])
+        out = torch.empty_like(bs)
+        self._call(self.lib.dll.smhip_addition_merge(self.ctx.h, k, ptrs, bs.data_ptr(), _DTYPE_CODE[dtype], bs.numel(),
+                                                     1 if sign_agreement else 0, out.data_ptr(), self._stream()))
+        return out
+
     # -- A1 - A13 fused ------------------------------------------------------------------
     def merge_layer(self, finetunes: Sequence[torch.Tensor], bases: Sequence[torch.Tensor], alphas: Sequence[float],
                     base_out: torch.Tensor, target_norm_offset: float = 1e-10, cull_start_pct: float = 0.20,
                     cutoff_pct: float = 0.08, t_sum: float = 1.0, want_delta: bool = False,
-                    layer_name: str = "layer"):
+                    layer_name: str = "layer", b: float = 0.1):
         k = len(finetunes)
         if k < 1 or k > _lib.MAX_MODELS:
             raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
@@ -221,6 +243,7 @@ class Engine:
         desc.cull_start_pct = float(cull_start_pct)
         desc.cutoff_pct = float(cutoff_pct)
         desc.t_sum = float(t_sum)
+        desc.b = float(b)
         out = torch.empty(bo.shape, dtype=torch.bfloat16, device=self.device)
         delta = torch.empty(bo.shape, dtype=torch.float32, device=self.device) if want_delta else None
         rep = LayerReport()
