@@ -201,7 +201,51 @@ def gen_cli(manifest):
     save_file(store, str(OUT / "g8_cli.safetensors"))
 
 
+def gen_addition(manifest):
+    """G9: the reference's AdditionMerge / TaskAdditionMerge on seeded tensors (their own tests pin
+    only all-ones cases: tests/merge/test_addition.py:92,139,186,233, test_taskaddition.py:45-93)."""
+    from shard.merge.addition import AdditionMerge
+    from shard.merge.taskaddition import TaskAdditionMerge
+    store = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for case in gi.ADDITION_CASES:
+            base, fts = gi.addition_inputs(case)
+            tensors = {"org/base": base}
+            for i, t in enumerate(fts):
+                tensors[f"org/ft{i}"] = t
+            cfg = MergeConfig(
+                finetune_merge=[MergeModel(model=f"org/ft{i}", base="org/base") for i in range(len(fts))],
+                output_base_model="org/base", output_dir=str(Path(tmp) / "out"), device="cpu",
+                cache_dir=str(Path(tmp) / "cache"), storage_dir=str(Path(tmp) / "storage"))
+            idx = HFMultiModelIndex(download_manager=DownloadManager(storage_path=Path(tmp) / "storage"),
+                                    cache_path=Path(tmp) / "cache_idx")
+
+            def fake_get(model_uri, tensor_name, device="cpu"):
+                p = AsyncMock()
+                p.get = AsyncMock(return_value=tensors[model_uri].clone())
+                return p
+
+            sl = ShardLayer(layer_order_idx=1, shard_name="model-00001.safetensors", layer_name="model.layers.0.w", written=False)
+            for tag, cls in (("addition", AdditionMerge), ("task_addition", TaskAdditionMerge)):
+                merger = cls(config=cfg, index_manager=idx)
+
+                async def go():
+                    with patch.object(idx, "get_tensor", side_effect=fake_get):
+                        return await merger._merge_layer(sl, device="cpu")
+
+                out = asyncio.run(go())
+                store[f"{case['id']}.{tag}"] = out.contiguous().clone()
+            manifest["inputs"][case["id"]] = gi.checksum(base) + sum((gi.checksum(t) for t in fts), [])
+    save_file(store, str(OUT / "g9_addition.safetensors"))
+
+
 def main():
+    if "--only-addition" in sys.argv:            # add G9 without touching the other fixtures
+        manifest = json.load(open(OUT / "manifest.json"))
+        gen_addition(manifest)
+        with open(OUT / "manifest.json", "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "inputs": {}}
     gen_fft(manifest)
     gen_interp(manifest)
@@ -210,6 +254,7 @@ def main():
     gen_pairs_sched(manifest)
     gen_layers(manifest)
     gen_cli(manifest)
+    gen_addition(manifest)
     with open(OUT / "manifest.json", "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     total = sum(p.stat().st_size for p in OUT.glob("*.safetensors"))

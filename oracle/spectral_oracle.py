@@ -468,6 +468,28 @@ def merge_layer(
 
 
 # --------------------------------------------------------------------------
+# N3 - AdditionMerge / TaskAdditionMerge
+# --------------------------------------------------------------------------
+def addition_merge(finetunes: Sequence[torch.Tensor], base: torch.Tensor) -> torch.Tensor:
+    """reference shard/merge/addition.py:70-76: deltas relative to output_base_model's tensor,
+    accumulated one by one in the tensors' dtype; the base is not added back."""
+    out = torch.zeros_like(base)
+    for ft in finetunes:
+        out += ft - base
+    return out
+
+
+def task_addition_merge(finetunes: Sequence[torch.Tensor], base: torch.Tensor) -> torch.Tensor:
+    """reference shard/merge/taskaddition.py:69-79: keep, per element, the deltas whose sign is
+    the sign of the sum of signs; sum them."""
+    stack = torch.stack([ft - base for ft in finetunes], dim=0)
+    signs = torch.sign(stack)
+    majority = torch.sum(signs, dim=0).sign()
+    keep = signs == majority.unsqueeze(0)
+    return torch.sum(stack * keep, dim=0)
+
+
+# --------------------------------------------------------------------------
 # synthetic inputs shared by tests / bench (SURVEY section 8(d))
 # --------------------------------------------------------------------------
 SIGMAS = (0.002, 0.003, 0.0025, 0.004)

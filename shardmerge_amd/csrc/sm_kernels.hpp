@@ -211,6 +211,7 @@ struct F1Params {
     int R2;                // transforms per slab: work-group w handles "rows" w + g*R2, g = 0..3
     int rowpair;           // 1: row-pair mode (a = row 2w, b = row 2w+1 of one tensor; row_stride = 2C)
     int Rcol;              // column length R (the folded twiddles are W_R)
+    size_t slab_elems;     // float4 per k1 slab of T1
     const cf2* twR;        // exp(-2 pi i j / R), j < R
 };
 
@@ -472,7 +473,8 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
 // columns (k1, bin).  The spectrum planes then hold each bin column in the order
 // [k1][k2] instead of k - every consumer between the transforms is order-blind inside a
 // column, and the inverse column pass reads that order back (k_i1, FOLD).
-// T1 here: element (n2, k1, bin) at ((n2 / ilv) * 4 * pitch4 + k1 * pitch4 + bin) * ilv + n2 % ilv.
+// T1 here is slab-major: element (n2, k1, bin) at k1 * slab_elems + ((n2 / ilv) * pitch4 + bin) * ilv + n2 % ilv
+// (the column pass then strides by one real row pitch inside a 1/4-size slab, as the plain layout does).
 // =====================================================================
 #ifndef SM_F1Q_QB
 #define SM_F1Q_QB 1          // 16-byte loads per operand in flight per batch (register budget: 128)
@@ -633,8 +635,8 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
 #pragma unroll
         for (int k1 = 1; k1 < 4; ++k1) { wA[k1] = p.twR[(size_t)n2A * k1]; wB[k1] = p.twR[(size_t)n2B * k1]; }
         const bool has_b = p.b.x != nullptr;
-        cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * 4 * p.pitch4 * p.ilv + (unit % p.ilv);
-        const size_t slabstride = (size_t)p.pitch4 * p.ilv;
+        cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * p.pitch4 * p.ilv + (unit % p.ilv);
+        const size_t slabstride = p.slab_elems;                  // slab-major: [k1][unit][bin]
         auto emit = [&](int k, const float* are, const float* aim, const float* bre, const float* bim) {
             SM_SCHED_FENCE();                      // one bin's butterflies at a time (register pressure)
             float ar[4], ai[4], br[4], bi[4];
@@ -694,6 +696,7 @@ struct F2Params {
     int slab;              // virtual columns per k1 (the real T1 pitch in float4)
     int Cb_real;           // bins per slab that exist (C/2 + 1)
     int Rfull;             // 4 * R: a bin column of the planes
+    size_t slab_elems;     // float4 per k1 slab of T1 (slab-major: the row stride stays one real pitch)
 };
 // virtual column v of a folded column pass -> plane offset of its first element, real bin (or -1)
 SM_HD int fold_bin(int v, int slab, int Cb_real, int R2, int Rfull, size_t& off) {
@@ -761,7 +764,13 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                     const int m = lane + (q / ILV) * 2 * T;               // row group
                     const int n = m * ILV + q % ILV;
                     cf4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (n < R && k2 < p.Cb) v = p.t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
+                    if constexpr (FOLD) {
+                        // slab-major T1: virtual column k2 = (k1, bin) lives in slab k1, row pitch = slab
+                        if (n < R && k2 < p.Cb)
+                            v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)m * p.slab + (k2 % p.slab)) * ILV + q % ILV];
+                    } else {
+                        if (n < R && k2 < p.Cb) v = p.t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
+                    }
                     s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
                 }
             };
@@ -912,6 +921,7 @@ struct F2SParams {
     float* re; float* im;  // destination planes [Cb][R] (im unused when !role_a)
     unsigned long long* hist;
     int slab, Cb_real, Rfull;   // FOLD variant: as F2Params
+    size_t slab_elems;
 };
 template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
@@ -941,7 +951,11 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         for (int q = 0; q < EMAX / 2; ++q) {
             const int m = lane + q * T;
             cf4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < half && k2 < p.Cb) v = p.t1[(size_t)m * p.pitch4 + k2];
+            if constexpr (FOLD) {
+                if (m < half && k2 < p.Cb) v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + (size_t)m * p.slab + (k2 % p.slab)];
+            } else {
+                if (m < half && k2 < p.Cb) v = p.t1[(size_t)m * p.pitch4 + k2];
+            }
             s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
         }
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;

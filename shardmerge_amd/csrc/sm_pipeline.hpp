@@ -70,6 +70,9 @@ SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(
 #ifndef SM_R14336
 #define SM_R14336 16, 16, 8, 7
 #endif
+#ifndef SM_R7168
+#define SM_R7168 32, 32, 7          // measured on MI355X as the folded column plan: 16,16,4,7 is 8 % slower
+#endif
 #ifndef SM_T8192
 #define SM_T8192 256
 #define SM_W8192 4
@@ -88,7 +91,7 @@ SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(
     X(SPlan<3584, 128, false, 4, 16, 32, 7>)       \
     X(SPlan<5120, 256, false, 4, 16, 16, 4, 5>)    \
     X(SPlan<6144, 256, false, 4, 16, 16, 8, 3>)    \
-    X(SPlan<7168, 256, false, 4, 16, 16, 4, 7>)    \
+    X(SPlan<7168, 256, false, 4, SM_R7168>)    \
     X(SPlan<12288, 512, false, 4, 16, 16, 16, 3>)  \
     X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>) \
     X(SPlan<27648, 1024, false, 4, 32, 32, 3, 3, 3>) \
@@ -444,7 +447,7 @@ class Pipeline {
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
-        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr;
+        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g);
         if (g.fold == 4) {
             if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
             FftPlanDev colp;
@@ -468,6 +471,8 @@ class Pipeline {
     static size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
     // rows (2m, 2m+1) of ONE signal as the two operands of the two-for-one row transform:
     // T1[m][k] = (spectrum of row 2m, spectrum of row 2m+1).  R must be even.
+    // float4 per k1 slab of the folded T1 (R/4 rows of one real pitch)
+    static size_t fold_slab_elems(const Geo& g) { return round_up((size_t)g.R / 4, 8) * (size_t)g.pitch4; }
     int run_f1_rowpairs(const Geo& g, const SigDesc& sig) {
         F1Params p;
         int rc = get_plan(g.C, p.plan);
@@ -481,7 +486,7 @@ class Pipeline {
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
-        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr;
+        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g);
         if (g.fold == 4) {
             if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
             FftPlanDev colp;
@@ -504,7 +509,7 @@ class Pipeline {
         if (rc) return rc;
         p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4 * g.fold; p.R = Rt; p.C = g.C;
         p.Cb = g.fold == 4 ? 4 * g.pitch4 : g.C / 2 + 1;
-        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R;
+        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R; p.slab_elems = fold_slab_elems(g);
         p.role_a = role_a ? 1 : 0; p.scale = scale;
         p.re = plane(g, role_a ? P_REA : P_REB); p.im = plane(g, P_IMA);
         p.hist = hist ? d_hist() : nullptr;
@@ -562,7 +567,7 @@ class Pipeline {
         int rc = get_plan(g.R, p.plan);
         if (rc) return rc;
         if (g.R == 1) {
-            p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = 1;
+            p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = 1; p.slab_elems = 0;
             p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4; p.ilv = 1; p.R = 1; p.C = g.C; p.Cb = g.C / 2 + 1; p.nsig = 2;
             p.swap = swap; p.scale[0] = scale0; p.scale[1] = scale1;
             p.reA = plane(g, P_REA); p.imA = plane(g, P_IMA); p.reB = plane(g, P_REB);
@@ -570,7 +575,7 @@ class Pipeline {
             be.template launch<KF2R1>(std::max(1, std::min(64, (p.Cb + 255) / 256)), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, p, stream);
             return SMHIP_OK;
         }
-        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R;
+        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R; p.slab_elems = fold_slab_elems(g);
         if (g.fold == 4) {
             // R2-point transforms on 4 * pitch4 virtual columns (k1, bin); see k_f1q
             if ((rc = get_plan(g.R / 4, p.plan))) return rc;

@@ -131,6 +131,32 @@ LAYER_CASES = [
 ]
 
 
+# G9: AdditionMerge / TaskAdditionMerge - every tensor goes through the same path
+ADDITION_CASES = [
+    {"id": "add_bf16_k2", "shape": (64, 96), "k": 2, "dtype": "bfloat16", "seed": 300},
+    {"id": "add_bf16_k3", "shape": (48, 128), "k": 3, "dtype": "bfloat16", "seed": 310},
+    {"id": "add_f32_k2", "shape": (32, 40), "k": 2, "dtype": "float32", "seed": 320},
+    {"id": "add_f16_k3", "shape": (40, 64), "k": 3, "dtype": "float16", "seed": 330},
+    {"id": "add_bf16_ragged_k4", "shape": (5, 7), "k": 4, "dtype": "bfloat16", "seed": 340},
+    {"id": "add_bf16_1d_k2", "shape": (1000,), "k": 2, "dtype": "bfloat16", "seed": 350},
+]
+
+
+def addition_inputs(case):
+    """-> (base, [finetunes]) in the case's dtype; deltas large and small, some exactly zero, so that
+    signs tie, cancel and survive the 16-bit rounding of every step."""
+    dt = getattr(torch, case["dtype"])
+    shape, seed = case["shape"], case["seed"]
+    base = _randn(shape, seed, 0.05).to(dt)
+    fts = []
+    for i in range(case["k"]):
+        d = _randn(shape, seed + 1 + i, 0.01)
+        zero = _randn(shape, seed + 20 + i, 1.0) > 0.8          # 20 % of the deltas exactly zero
+        d = torch.where(zero, torch.zeros_like(d), d)
+        fts.append((base.float() + d).to(dt))
+    return base, fts
+
+
 def layer_inputs(case):
     """-> (tensors by model uri, MergeModel kwargs list, config kwargs, layer name)"""
     shape, seed, k = case["shape"], case["seed"], case["k"]

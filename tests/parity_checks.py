@@ -199,8 +199,10 @@ def check_layer_steps(rep, tr, numel, reported_fields=True):
             tol = LATER_ROUND_CULL_TOL if n_inter[i] == 1 else BOTH_INTER_CULL_TOL
             assert abs(info.cull_threshold - bt.cull_threshold) <= tol * bt.cull_threshold, \
                 f"step {i} cull threshold {info.cull_threshold} vs {bt.cull_threshold}"
-            assert abs(info.n_slerp - bt.n_slerp) <= LATER_ROUND_NSLERP_TOL * bt.n_slerp, f"step {i} n_slerp"
-            assert abs(info.dot - bt.dot) <= LATER_ROUND_DOT_TOL, f"step {i} dot {info.dot} vs {bt.dot}"
+            both = 2.0 if n_inter[i] == 2 else 1.0          # two noisy inputs: twice the irreproducible membership
+            assert abs(info.n_slerp - bt.n_slerp) <= both * LATER_ROUND_NSLERP_TOL * bt.n_slerp, \
+                f"step {i} n_slerp {info.n_slerp} vs {bt.n_slerp}"
+            assert abs(info.dot - bt.dot) <= both * LATER_ROUND_DOT_TOL, f"step {i} dot {info.dot} vs {bt.dot}"
 
 
 def masked_spectral_check(delta, tr, tol_outside=OUTSIDE_CULLED_TOL):

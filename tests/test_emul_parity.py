@@ -343,3 +343,29 @@ def test_folded_column_pass(engine, k):
     else:
         pc.masked_spectral_check(delta, trx, tol_outside=1e-3)
     assert so.rel_err(out.float(), refx.float()) < (1e-3 if k == 2 else 5e-3)
+
+
+# ---- N3: AdditionMerge / TaskAdditionMerge (bit-exact: elementwise work in the tensors' dtype) ----
+@pytest.mark.parametrize("case", gi.ADDITION_CASES, ids=lambda c: c["id"])
+def test_addition_operators_bit_exact(engine, golden, case):
+    base, fts = gi.addition_inputs(case)
+    for tag, agree in (("addition", False), ("task_addition", True)):
+        out = engine.addition_merge(fts, base, sign_agreement=agree).cpu()
+        ref = golden.get("g9_addition.safetensors", f"{case['id']}.{tag}")
+        assert out.dtype == ref.dtype and out.shape == ref.shape
+        assert torch.equal(out, ref), f"{tag}: {(out != ref).sum().item()} of {out.numel()} elements differ"
+
+
+def test_addition_known_answers_of_the_reference_tests(engine):
+    """The reference's own known-answer cases (tests/merge/test_addition.py:92,139,186,
+    tests/merge/test_taskaddition.py:45-93 and its disagreement case)."""
+    one = torch.ones(4, 4)
+    assert torch.allclose(engine.addition_merge([one * 2, one * 3], one).cpu(), one * 3.0)
+    assert torch.allclose(engine.addition_merge([one, one], one).cpu(), torch.zeros(4, 4))
+    assert torch.allclose(engine.addition_merge([one * 0, one * -1], one).cpu(), one * -3.0)
+    assert torch.allclose(engine.addition_merge([one * 4], one).cpu(), one * 3.0)                      # single model, alpha unused
+    assert torch.allclose(engine.addition_merge([one * 2, one * 3], one, sign_agreement=True).cpu(), one * 3.0)
+    # signs disagree: sum of signs is 0 -> nothing matches sign 0 unless a delta is itself 0
+    assert torch.allclose(engine.addition_merge([one * 2, one * 0], one, sign_agreement=True).cpu(), torch.zeros(4, 4))
+    # two against one: the majority sign's deltas survive
+    assert torch.allclose(engine.addition_merge([one * 2, one * 3, one * 0], one, sign_agreement=True).cpu(), one * 3.0)

@@ -378,8 +378,11 @@ def test_real_model_shapes_k2_vs_exact_norm_oracle(engine, shape):
         refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
     out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
     pc.check_layer_steps(rep, trx, out.numel())
-    d_total, d_resid = pc.spectral_residual(delta.cpu(), trx.merged_delta)
-    assert d_resid < 2e-5, f"beyond the tie bins: {d_resid:.2e}"
+    # the number of bins that sit ON a threshold (within the ~1e-7 by which two correct FFTs differ)
+    # grows with the tensor: 58 M elements have ~10-30 of them (tools/fold_check.py) - beyond those
+    # the agreement is 4e-7
+    d_total, d_resid = pc.spectral_residual(delta.cpu(), trx.merged_delta, drop=64)
+    assert d_resid < 5e-6, f"beyond the tie bins: {d_resid:.2e}"
     assert d_total < 1e-3, f"merged delta (SURVEY 8d's stricter bar): {d_total:.2e}"
     assert so.rel_err(out.cpu().float(), refx.float()) < 1e-3          # BASELINE: 1e-3 on the bf16 output
     mism = (out.cpu().view(torch.int16) != refx.view(torch.int16)).float().mean().item()
