@@ -369,3 +369,20 @@ def test_addition_known_answers_of_the_reference_tests(engine):
     assert torch.allclose(engine.addition_merge([one * 2, one * 0], one, sign_agreement=True).cpu(), torch.zeros(4, 4))
     # two against one: the majority sign's deltas survive
     assert torch.allclose(engine.addition_merge([one * 2, one * 3, one * 0], one, sign_agreement=True).cpu(), one * 3.0)
+
+
+def test_linear_blend_branch_with_a_larger_b(engine):
+    """merge_options.b (N4): merge_tensors_fft2_slerp blends linearly, R = Fa + t Fb, when the norm
+    ratio is below b (functions.py:196-202).  Unreachable at the reference's b = 0.1 (the layer
+    routes ratios < 0.1 to Arithmetic-FFT first); with b = 0.5 a ratio of ~0.25 takes it."""
+    from oracle import spectral_oracle as so
+    base, fts = so.synthetic_layer(128, 256, 2, seed=61, sigmas=(0.004, 0.001))
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr, ratio_b=0.5)
+    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True, b=0.5)
+    assert rep.branches == tr.branches == ["linear"]
+    assert so.rel_err(delta.cpu(), tr.merged_delta) < 5e-6
+    assert (out.cpu().view(torch.int16) != ref.view(torch.int16)).float().mean().item() < 2e-3
+    # and the default keeps the SLERP branch
+    out2, rep2 = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base)
+    assert rep2.branches == ["slerp"]

@@ -431,3 +431,59 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     assert rec["as_is"]["out_rel_err"] < 1e-3
     # delta level vs the as-is reference: bounded by what the norm artefact does to the reference itself
     assert rec["as_is"]["delta_rel_err"] < 1e-3 + 1.5 * rec["reference_self_shift"]["delta"]
+
+
+# ---- N3 / N4 on the device ------------------------------------------------------------------------
+@pytest.mark.parametrize("case", gi.ADDITION_CASES, ids=lambda c: c["id"])
+def test_addition_operators_bit_exact_on_device(engine, golden, case):
+    emul_tier.test_addition_operators_bit_exact(engine, golden, case)
+
+
+def test_addition_known_answers_and_linear_branch_on_device(engine):
+    emul_tier.test_addition_known_answers_of_the_reference_tests(engine)
+    emul_tier.test_linear_blend_branch_with_a_larger_b(engine)
+
+
+def test_addition_full_size_against_torch_on_device(engine):
+    """8192 x 8192 bf16, K = 3: the kernel against the reference's formula evaluated by torch on
+    the same device tensors (elementwise bf16 ops round like the CPU's: bit-exact expected)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = (torch.randn(8192, 8192, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(8192, 8192, generator=g, device="cuda") * 0.01).to(torch.bfloat16) for _ in range(3)]
+    out = engine.addition_merge(fts, base)
+    ref = torch.zeros_like(base)
+    for ft in fts:
+        ref += ft - base
+    assert torch.equal(out, ref)
+    out_t = engine.addition_merge(fts, base, sign_agreement=True)
+    stack = torch.stack([ft - base for ft in fts], dim=0)
+    signs = torch.sign(stack)
+    keep = signs == torch.sum(signs, dim=0).sign().unsqueeze(0)
+    assert torch.equal(out_t, torch.sum(stack * keep, dim=0))
+
+
+# ---- the folded column pass on the device ------------------------------------------------------------
+@pytest.mark.parametrize("k", [2, 3])
+def test_folded_column_pass_on_device(engine, k):
+    emul_tier.test_folded_column_pass(engine, k)
+
+
+def test_folded_column_pass_is_taken_for_the_mlp_shapes(engine):
+    """28672 x 8192 / 14336 x 4096 (Llama-3 MLP tensors) run the folded kernels by default; the
+    result must equal the plain path's up to threshold-tie bins (same data, same thresholds)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shape = (14336, 4096)
+    base = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g, device="cuda") * s).to(torch.bfloat16) for s in (0.002, 0.003)]
+    out1, rep1, d1 = engine.merge_layer(fts, [base, base], [0.3, 0.5], base, want_delta=True)
+    engine.ctx.debug_option("fold_columns", 0)
+    try:
+        out0, rep0, d0 = engine.merge_layer(fts, [base, base], [0.3, 0.5], base, want_delta=True)
+    finally:
+        engine.ctx.debug_option("fold_columns", 1)
+    i1, i0 = rep1.infos[0], rep0.infos[0]
+    assert abs(i1.cutoff_threshold - i0.cutoff_threshold) <= 2e-6 * i0.cutoff_threshold
+    assert abs(i1.cull_threshold - i0.cull_threshold) <= 2e-6 * i0.cull_threshold
+    assert abs(i1.n_slerp - i0.n_slerp) <= 64
+    assert not torch.equal(d1, d0)                    # two different kernel paths did run
+    assert pc.spectral_residual(d1.cpu(), d0.cpu(), drop=64)[1] < 2e-6

@@ -259,3 +259,50 @@ def test_unsupported_lengths_fail_before_any_layer_is_merged(tmp_path, emul):
     res = CliRunner().invoke(cli, ["merge", str(cfg_path)])
     assert res.exit_code != 0
     assert not list((tmp_path / "merged").glob("*.safetensors"))          # nothing was written
+
+
+# ---- N3 / N4: operator choice and b through the YAML ------------------------------------------------
+def test_merge_options_operator_and_b(tmp_path):
+    doc = {"output_base_model": "o/b", "finetune_merge": [{"model": "o/f", "base": "o/b"}], "output_dir": "out"}
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(doc))
+    assert MergeConfig.from_yaml(p).operator == "fourier"
+    doc["merge_options"] = {"operator": "task_addition", "b": 0.3}
+    p.write_text(yaml.safe_dump(doc))
+    cfg = MergeConfig.from_yaml(p)
+    assert cfg.operator == "task_addition" and cfg.merge_options == {"b": 0.3}
+    from shardmerge_amd.merge import operator_class
+    from shardmerge_amd.merge.addition import AdditionMerge
+    from shardmerge_amd.merge.taskaddition import TaskAdditionMerge
+    assert operator_class("task_addition") is TaskAdditionMerge and operator_class("addition") is AdditionMerge
+    assert operator_class("fourier") is FourierMerge
+    doc["merge_options"] = {"operator": "median"}
+    p.write_text(yaml.safe_dump(doc))
+    with pytest.raises(click.BadParameter, match="operator"):
+        MergeConfig.from_yaml(p)
+
+
+@pytest.mark.parametrize("op", ["addition", "task_addition"])
+def test_cli_with_the_addition_operators(tmp_path, emul, op):
+    """`merge CONFIG` with merge_options.operator: every tensor (embeddings and head too, as in the
+    reference: these operators have no passthrough) becomes the (sign-agreeing) sum of deltas."""
+    from oracle import spectral_oracle as so
+    from shardmerge_amd.__main__ import cli
+    cfg_path = gi.write_cli_model(tmp_path)
+    doc = yaml.safe_load(cfg_path.read_text())
+    doc["merge_options"] = {"operator": op}
+    cfg_path.write_text(yaml.safe_dump(doc))
+    res = CliRunner().invoke(cli, ["merge", str(cfg_path)])
+    assert res.exit_code == 0, res.output
+    out_dir = tmp_path / "merged"
+    readme = (out_dir / "README.md").read_text()
+    assert "Merged Model" in readme and "org/base" in readme and ("sign agreement" in readme) == (op == "task_addition")
+    models = [gi.cli_model_tensors(i) for i in range(3)]
+    fn = so.task_addition_merge if op == "task_addition" else so.addition_merge
+    n = 0
+    for shard in gi.CLI_SHARDS:
+        with safe_open(str(out_dir / shard), framework="pt") as f:
+            for k in f.keys():
+                assert torch.equal(f.get_tensor(k), fn([models[1][k], models[2][k]], models[0][k]).to(torch.bfloat16)), k
+                n += 1
+    assert n == sum(len(v) for v in gi.CLI_SHARDS.values())
