@@ -267,6 +267,12 @@ def main():
     for _ in range(1, max(1, args.streams)):
         engines.append((Engine(device=device), torch.cuda.Stream(device=device)))
 
+    # tuning experiments only: SMHIP_DEBUG=fold_columns=0,spectral_intermediates=0 (library test hooks)
+    for item in filter(None, os.environ.get("SMHIP_DEBUG", "").split(",")):
+        key, val = item.split("=")
+        for eng, _ in engines:
+            eng.ctx.debug_option(key, int(val))
+
     shapes, desc = workload_shapes(args.workload, args.blocks)
     k = args.k
     # stage inputs: rank 0 owns the shared base; ONE RCCL broadcast distributes it
