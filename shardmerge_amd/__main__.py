@@ -28,7 +28,8 @@ async def run_merge(config: MergeConfig, device: str, clean_cache: bool, **kwarg
     With more than one rank (torchrun) the tensor list is partitioned over the GPUs."""
     index_manager = LocalModelIndex(storage_path=config.storage_path, cache_path=config.cache_path)
     from . import distributed
-    if distributed.world_size() > 1:
+    import os
+    if distributed.world_size() > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1":
         await distributed.run_partitioned_merge(config, index_manager, device)
         return
     from .merge import operator_class

@@ -97,7 +97,78 @@ def init_process_group(device: torch.device):
     return dist
 
 
+def _shard_complete(path: Path, expected) -> bool:
+    """An output shard that exists with exactly the expected tensors (written atomically)."""
+    if not path.exists():
+        return False
+    try:
+        with open(path, "rb") as fh:
+            n = int.from_bytes(fh.read(8), "little")
+            header = json.loads(fh.read(n))
+    except Exception:
+        return False
+    return {k for k in header if k != "__metadata__"} == set(expected)
+
+
+class _BaseShardReader:
+    """The root rank's side of the base-shard broadcast: the shard's block tensors are read with
+    positional reads (4 threads) into ONE pinned buffer and go to the device with ONE copy; the
+    next shard this rank is root of is read in the background while the current one is merged."""
+
+    def __init__(self, index: LocalModelIndex, uri: str, pinned: bool):
+        from concurrent.futures import ThreadPoolExecutor
+        self.index, self.uri, self.pinned = index, uri, pinned
+        self.pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="shardmerge-base")
+        self.pending = {}
+
+    def _read(self, shard: str, layout, total: int) -> torch.Tensor:
+        from .loader import ShardFile
+        host = torch.empty(max(total, 1), dtype=torch.uint8, pin_memory=self.pinned)
+        f = ShardFile(self.index.storage_path / self.uri / shard)
+        try:
+            jobs = [self.pool.submit(f.read_into, name, host[off:off + nbytes]) for name, (off, nbytes) in layout.items() if nbytes]
+            for j in jobs:
+                j.result()
+        finally:
+            f.close()
+        return host
+
+    def start(self, shard: str, layout, total: int):
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["host"] = self._read(shard, layout, total)
+            except BaseException as exc:          # surfaced by take()
+                box["error"] = exc
+        t = threading.Thread(target=run, name="shardmerge-base-read", daemon=True)
+        t.start()
+        self.pending[shard] = (t, box)
+
+    def take(self, shard: str, layout, total: int) -> torch.Tensor:
+        if shard not in self.pending:
+            return self._read(shard, layout, total)
+        t, box = self.pending.pop(shard)
+        t.join()
+        if "error" in box:
+            raise box["error"]
+        return box["host"]
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
 async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, device: str):
+    """One rank of the N-rank merge.  Per base shard, in file order:
+      1. the root (shard index mod N) reads the shard's block tensors and ONE broadcast (RCCL over
+         xGMI) hands them to every rank - the only collective of the data path, no reduction;
+      2. every rank merges the tensors the plan (LPT on algorithmic bytes) gave it; its finetune
+         tensors are prefetched (loader.py);
+      3. results leave for the shard's writer rank (= the root): its own through the asynchronous
+         pinned copy of ModelWriter, the other ranks' with one point-to-point message each (device
+         to device) - no part files, every tensor is written to disk once.
+    A shard whose output file is already complete is skipped by all ranks (resume)."""
     world, me = world_size(), rank()
     if ENGINE_FACTORY is not None:
         engine = ENGINE_FACTORY()
@@ -106,31 +177,36 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
         torch.cuda.set_device(local_rank())
         engine = get_engine(f"cuda:{local_rank()}")
     dev = engine.device
-    dist = init_process_group(dev)
+    on_gpu = dev.type == "cuda"
+    use_dist = world > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1"
+    dist = init_process_group(dev) if use_dist else None
 
     merger = FourierMerge(config=config, index_manager=index, engine=engine)
     await merger.initialize()
     base_uri = config.output_base_model
     layer_order = index.get_layer_order(base_uri)
+    rank_of = {n: i for i, n in enumerate(layer_order)}
     weight_map = index.model_indexes[base_uri]["weight_map"]
     shards = sorted(set(weight_map.values()))
     out_dir = config.output_path
     out_dir.mkdir(parents=True, exist_ok=True)
-    # part files of an earlier (crashed) run - another partition, world size or configuration -
-    # must never be assembled into this run's shards
+    # leftovers of an earlier (crashed) run must never reach this run's shards
     if me == 0:
         for stale in list(out_dir.glob(".part-*")) + list(out_dir.glob(".tmp-*")):
             stale.unlink()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
 
     # ---- plan: the same on every rank --------------------------------------------------
     metas = {s: _tensor_meta(index, base_uri, s) for s in shards}
+    names_of = {s: sorted((n for n in weight_map if weight_map[n] == s), key=rank_of.get) for s in shards}
+    done = {s: _shard_complete(out_dir / s, names_of[s]) for s in shards}
     names, costs = [], []
     for s in shards:
-        for name in sorted((n for n in weight_map if weight_map[n] == s), key=layer_order.index):
-            sl = ShardLayer(layer_order.index(name), s, name, False)
-            number = sl.layer_number
+        if done[s]:
+            continue
+        for name in names_of[s]:
+            number = ShardLayer(rank_of[name], s, name, False).layer_number
             numel = 1
             for d in metas[s][name][0]:
                 numel *= d
@@ -142,17 +218,19 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             names.append((s, name))
             costs.append(cost)
     owner = partition_lpt(costs, world)
-    mine = {names[i] for i in range(len(names)) if owner[i] == me}
+    owner_of = {names[i]: owner[i] for i in range(len(names))}
+    mine = {key for key, o in owner_of.items() if o == me}
     logger.info(f"rank {me}/{world}: {len(mine)} of {len(names)} tensors, "
-                f"{sum(c for c, o in zip(costs, owner) if o == me) / 1e9:.2f} GB algorithmic traffic")
+                f"{sum(c for c, o in zip(costs, owner) if o == me) / 1e9:.2f} GB algorithmic traffic"
+                + (f"; {sum(done.values())} shard(s) already complete" if any(done.values()) else ""))
 
     # ---- this rank's finetune tensors are prefetched in processing order (loader.py); the base
     # comes from the broadcast, passthrough tensors from whichever model provides them
-    my_order = [(s, name) for s in shards
-                for name in sorted((n for (ss, n) in mine if ss == s), key=layer_order.index)]
+    todo = [s for s in shards if not done[s]]
+    my_order = [(s, name) for s in todo for name in names_of[s] if (s, name) in mine]
     schedule = []
     for (s, name) in my_order:
-        sl = ShardLayer(layer_order.index(name), s, name, False)
+        sl = ShardLayer(rank_of[name], s, name, False)
         if sl.layer_number >= 0:
             models = [m for m in config.finetune_merge if m.use_layer_index(sl.layer_number)]
             uris = [m.model for m in models] + [m.base for m in models if m.base != base_uri]
@@ -166,90 +244,101 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
         loader.start(schedule)
         merger._loader = loader
     pos = {key: i for i, key in enumerate(my_order)}
-    import concurrent.futures
-    part_writer = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="shardmerge-part")
-    part_jobs = []
 
-    # ---- per base shard: one broadcast, then every rank merges its own tensors -----------
-    for si, s in enumerate(shards):
-        root = si % world
-        block = [n for n in metas[s] if ShardLayer(0, s, n, False).layer_number >= 0]
+    # the shards this rank writes: a buffered, asynchronous ModelWriter over exactly those
+    root_of = {s: si % world for si, s in enumerate(shards)}
+    my_shards = [s for s in todo if root_of[s] == me]
+    writer = None
+    if my_shards:
+        sub_index = {"metadata": index.model_indexes[base_uri].get("metadata", {}),
+                     "weight_map": {n: s for s in my_shards for n in names_of[s]}}
+        writer = ModelWriter(base_index=sub_index, output_path=out_dir, layer_order=layer_order,
+                             output_astype=config.output_astype, write_index=False)
+
+    def block_layout(s):
+        block = [n for n in names_of[s] if ShardLayer(0, s, n, False).layer_number >= 0]
         offs, total = {}, 0
         for n in block:                                   # 256-byte aligned slots
-            offs[n] = total
+            offs[n] = (total, metas[s][n][2])
             total += (metas[s][n][2] + 255) // 256 * 256
-        flat = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-        if me == root and total:
+        return block, offs, total
+
+    reader = _BaseShardReader(index, base_uri, pinned=on_gpu)
+    mine_as_root = [s for s in todo if root_of[s] == me]
+    if mine_as_root:
+        _, offs0, total0 = block_layout(mine_as_root[0])
+        reader.start(mine_as_root[0], offs0, total0)
+
+    try:
+        for s in todo:
+            root = root_of[s]
+            block, offs, total = block_layout(s)
+            flat = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+            if me == root and total:
+                host = reader.take(s, offs, total)
+                flat.copy_(host, non_blocking=True)
+                nxt = [q for q in mine_as_root if q > s]
+                if nxt:                                   # read the next base shard during this merge
+                    _, offs_n, total_n = block_layout(nxt[0])
+                    reader.start(nxt[0], offs_n, total_n)
+            if dist is not None and total:
+                dist.broadcast(flat, src=root)            # THE collective: RCCL over xGMI
+            views = {}
             for n in block:
-                t = index.load_tensor(base_uri, n).contiguous()
-                flat[offs[n]:offs[n] + metas[s][n][2]].copy_(t.view(torch.uint8).reshape(-1), non_blocking=False)
-        if world > 1 and total:
-            dist.broadcast(flat, src=root)              # the one collective: RCCL over xGMI
-        views = {}
-        for n in block:
-            shape, dt, nbytes = metas[s][n]
-            views[n] = flat[offs[n]:offs[n] + nbytes].view(_ST_DTYPES[dt]).reshape(shape)
+                shape, dt, nbytes = metas[s][n]
+                views[n] = flat[offs[n][0]:offs[n][0] + nbytes].view(_ST_DTYPES[dt]).reshape(shape)
 
-        merged: Dict[str, torch.Tensor] = {}
-        for (shard_name, name) in sorted(mine, key=lambda sn: layer_order.index(sn[1])):
-            if shard_name != s:
-                continue
-            sl = ShardLayer(layer_order.index(name), s, name, False)
-            if loader is not None:
-                loader.begin_layer(pos[(s, name)])
-            if sl.layer_number >= 0:
-                out = await _merge_block_tensor(merger, engine, sl, views[name])
-            else:
-                out = await merger._merge_layer(sl, str(dev))
-            merged[name] = out.detach().to("cpu").to(config.output_astype).contiguous()
-        if merged:
-            from safetensors.torch import save_file
-            # serialised in the background while the next shard is broadcast and merged
-            part_jobs.append(part_writer.submit(save_file, merged, str(out_dir / f".part-{me}-{s}"), {"format": "pt"}))
-        del flat, views
+            merged: Dict[str, torch.Tensor] = {}
+            for name in names_of[s]:
+                if (s, name) not in mine:
+                    continue
+                sl = ShardLayer(rank_of[name], s, name, False)
+                if loader is not None:
+                    loader.begin_layer(pos[(s, name)])
+                if sl.layer_number >= 0:
+                    out = await _merge_block_tensor(merger, engine, sl, views[name])
+                else:
+                    out = await merger._merge_layer(sl, str(dev))
+                out = out.detach().to(config.output_astype)
+                if me == root:
+                    writer.add_tensor(name, out)          # asynchronous pinned copy, written with the shard
+                else:
+                    merged[name] = out
+            # results of the other ranks travel to the writer rank, one message per rank
+            if dist is not None and world > 1:
+                for r in range(world):
+                    theirs = [n for n in names_of[s] if owner_of[(s, n)] == r]
+                    if r == root or not theirs:
+                        continue
+                    sizes = [metas[s][n][0] for n in theirs]
+                    numels = [int(torch.Size(sh).numel()) for sh in sizes]
+                    if me == r:
+                        buf = torch.cat([merged[n].reshape(-1) for n in theirs]) if len(theirs) > 1 else merged[theirs[0]].reshape(-1).contiguous()
+                        dist.send(buf, dst=root)
+                    elif me == root:
+                        buf = torch.empty(sum(numels), dtype=config.output_astype, device=dev)
+                        dist.recv(buf, src=r)
+                        o = 0
+                        for n, sh, ne in zip(theirs, sizes, numels):
+                            writer.add_tensor(n, buf[o:o + ne].view(sh))
+                            o += ne
+            del flat, views, merged
+    finally:
+        reader.close()
+        if loader is not None:
+            loader.close()
+            merger._loader = None
 
-    for job in part_jobs:
-        job.result()
-    part_writer.shutdown()
-    if loader is not None:
-        loader.close()
-        merger._loader = None
-    if world > 1:
-        dist.barrier()
-
-    # ---- assemble shards (CPU file I/O), index and README ----------------------------------
-    from safetensors import safe_open
-    from safetensors.torch import save_file
-    for si, s in enumerate(shards):
-        if si % world != me:
-            continue
-        tensors = {}
-        planned = {names[i][1]: owner[i] for i in range(len(names)) if names[i][0] == s}
-        for r in range(world):
-            part = out_dir / f".part-{r}-{s}"
-            if part.exists():
-                with safe_open(str(part), framework="pt") as fh:
-                    for k in fh.keys():
-                        if planned.get(k) != r:
-                            raise RuntimeError(f"{part.name} holds {k}, which the plan gave to rank {planned.get(k)}")
-                        tensors[k] = fh.get_tensor(k)
-        expected = {n for n in weight_map if weight_map[n] == s}
-        if set(tensors) != expected:
-            raise RuntimeError(f"Incomplete model output: shard {s} is missing {sorted(expected - set(tensors))}")
-        ordered = {k: tensors[k] for k in sorted(tensors, key=layer_order.index)}
-        tmp = out_dir / f".tmp-{me}-{s}"
-        save_file(ordered, str(tmp), metadata={"format": "pt"})
-        os.replace(tmp, out_dir / s)                     # a shard file is either absent or complete
-    if world > 1:
+    if writer is not None:
+        writer.finalize()                                 # raises if one of this rank's shards is incomplete
+    if dist is not None:
         dist.barrier()
     if me == 0:
-        for p in out_dir.glob(".part-*"):
-            p.unlink()
         with open(out_dir / "model.safetensors.index.json", "w") as fh:
             json.dump(index.model_indexes[base_uri], fh, indent=2)
         with open(out_dir / "README.md", "w") as fh:
             fh.write(merger.get_readme())
-    if world > 1:
+    if dist is not None:
         dist.barrier()
 
 

@@ -62,12 +62,15 @@ class ModelWriter:
     output_astype: torch.dtype
     written_shard_layers: Set[Tuple[str, str]] = field(default_factory=set)
     shard_to_tensors: Dict[str, Set[str]] = field(default_factory=dict)
+    write_index: bool = True        # False: a rank of the multi-GPU merge writes only its shards (rank 0 writes the index)
 
     def __post_init__(self):
         self.output_path = Path(self.output_path)
         self.output_path.mkdir(parents=True, exist_ok=True)
         self.index_path = self.output_path / "model.safetensors.index.json"
-        if self.index_path.exists():
+        if not self.write_index:
+            pass
+        elif self.index_path.exists():
             logger.info(f"Index already exists: {self.index_path}")
             with open(self.index_path) as fh:
                 self.base_index = json.load(fh)

@@ -16,6 +16,8 @@ from tests.emul.loader import emul_engine  # noqa: E402
 
 
 def main():
+    import logging
+    logging.basicConfig(level=logging.INFO)
     torch.set_num_threads(1)
     cfg = MergeConfig.from_yaml(sys.argv[1])
     distributed.ENGINE_FACTORY = emul_engine

@@ -68,6 +68,7 @@ def test_two_rank_merge_equals_single_process(tmp_path, monkeypatch):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
     a, b = one / "merged", two / "merged"
+    assert not list(b.glob(".part-*")) and not list(b.glob(".tmp-*"))      # results travel rank to rank, shards are written once
     assert sorted(p.name for p in a.iterdir()) == sorted(p.name for p in b.iterdir())
     assert (a / "README.md").read_text() == (b / "README.md").read_text()
     for shard in gi.CLI_SHARDS:
@@ -75,3 +76,35 @@ def test_two_rank_merge_equals_single_process(tmp_path, monkeypatch):
             assert list(fa.keys()) == list(fb.keys())
             for k in fa.keys():
                 assert torch.equal(fa.get_tensor(k), fb.get_tensor(k)), k
+
+
+def test_two_rank_merge_resumes_at_shard_granularity(tmp_path):
+    """A complete output shard from an earlier run is kept (its mtime does not change) and only
+    the missing shards are merged, on every rank consistently."""
+    from tests.emul.loader import build
+    build()
+    cfg = gi.write_cli_model(tmp_path)
+
+    def run():
+        port = free_port()
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+            procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(cfg)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        return "\n".join(outs)
+
+    run()
+    out = tmp_path / "merged"
+    shards = sorted(gi.CLI_SHARDS)
+    keep, redo = shards[0], shards[-1]
+    before = {s: (out / s).read_bytes() for s in shards}
+    stamp = (out / keep).stat().st_mtime_ns
+    (out / redo).unlink()
+    log = run()
+    assert "already complete" in log
+    assert (out / keep).stat().st_mtime_ns == stamp
+    assert {s: (out / s).read_bytes() for s in shards} == before

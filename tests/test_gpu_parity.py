@@ -489,3 +489,42 @@ def test_folded_column_pass_is_taken_for_the_mlp_shapes(engine):
     assert abs(i1.n_slerp - i0.n_slerp) <= 64
     assert not torch.equal(d1, d0)                    # two different kernel paths did run
     assert pc.spectral_residual(d1.cpu(), d0.cpu(), drop=64)[1] < 2e-6
+
+
+def test_partitioned_merge_through_rccl_world_size_1(tmp_path, golden):
+    """The multi-GPU product path (shardmerge_amd/distributed.py) with its collectives REAL: one
+    rank, backend nccl (= RCCL), process group initialised on the device, the base-shard
+    broadcast and the barriers executed.  (A one-GPU box cannot host two RCCL ranks; the N > 1
+    logic is covered by the 2-rank gloo test on CPU.)  Output must equal the single-process CLI's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    from safetensors import safe_open
+    repo = Path(__file__).resolve().parents[1]
+    cfg = gi.write_cli_model(tmp_path, device="cuda")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SHARDMERGE_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
+    res = subprocess.run([sys.executable, "-m", "shard", "merge", str(cfg), "--device", "cuda"], cwd=str(repo), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rank 0/1" in res.stderr + res.stdout                     # the partitioned path did run
+    out_dir = tmp_path / "merged"
+    want = golden.manifest["cli"]
+    assert sorted(p.name for p in out_dir.iterdir()) == want["files"]
+    assert json.load(open(out_dir / "model.safetensors.index.json")) == want["index"]
+    for shard in gi.CLI_SHARDS:
+        with safe_open(str(out_dir / shard), framework="pt") as f:
+            for k in f.keys():
+                ref = golden.get("g8_cli.safetensors", f"{shard}::{k}")
+                got = f.get_tensor(k)
+                assert got.dtype == ref.dtype and got.shape == ref.shape
+                if "layers" in k:
+                    assert so.rel_err(got.float(), ref.float()) < 2e-3
+                else:
+                    assert torch.equal(got, ref)
