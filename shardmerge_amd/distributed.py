@@ -181,7 +181,9 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     use_dist = world > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1"
     dist = init_process_group(dev) if use_dist else None
 
-    merger = FourierMerge(config=config, index_manager=index, engine=engine)
+    from .merge import operator_class
+    merger = operator_class(getattr(config, "operator", "fourier"))(config=config, index_manager=index, engine=engine)
+    fourier = isinstance(merger, FourierMerge)          # the other operators fetch the base themselves: nothing to broadcast
     await merger.initialize()
     base_uri = config.output_base_model
     layer_order = index.get_layer_order(base_uri)
@@ -210,8 +212,8 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             numel = 1
             for d in metas[s][name][0]:
                 numel *= d
-            if number in (INPUT_LAYER, OUTPUT_LAYER):
-                cost = 2 * numel                       # passthrough: a copy
+            if number in (INPUT_LAYER, OUTPUT_LAYER) or not fourier:
+                cost = 2 * numel * (1 if fourier else len(config.finetune_merge) + 2)      # a copy / one streaming pass
             else:
                 k = sum(1 for m in config.finetune_merge if m.use_layer_index(number))
                 cost = alg_bytes(numel, k)
@@ -231,7 +233,7 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     schedule = []
     for (s, name) in my_order:
         sl = ShardLayer(rank_of[name], s, name, False)
-        if sl.layer_number >= 0:
+        if sl.layer_number >= 0 and fourier:
             models = [m for m in config.finetune_merge if m.use_layer_index(sl.layer_number)]
             uris = [m.model for m in models] + [m.base for m in models if m.base != base_uri]
             schedule.append([(u, name) for u in dict.fromkeys(uris)])
@@ -256,7 +258,7 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
                              output_astype=config.output_astype, write_index=False)
 
     def block_layout(s):
-        block = [n for n in names_of[s] if ShardLayer(0, s, n, False).layer_number >= 0]
+        block = [n for n in names_of[s] if ShardLayer(0, s, n, False).layer_number >= 0] if fourier else []
         offs, total = {}, 0
         for n in block:                                   # 256-byte aligned slots
             offs[n] = (total, metas[s][n][2])
@@ -295,7 +297,7 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
                 sl = ShardLayer(rank_of[name], s, name, False)
                 if loader is not None:
                     loader.begin_layer(pos[(s, name)])
-                if sl.layer_number >= 0:
+                if sl.layer_number >= 0 and fourier:
                     out = await _merge_block_tensor(merger, engine, sl, views[name])
                 else:
                     out = await merger._merge_layer(sl, str(dev))
