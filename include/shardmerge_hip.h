@@ -111,6 +111,11 @@ typedef struct {
                                                the pair is blended linearly, R = F0 + t F1 (functions.py:164,196-202);
                                                unreachable at the default (the layer's own rule routes ratios < 0.1
                                                to Arithmetic-FFT first, fast_fourier.py:226) */
+    int norm_mode;                          /* 0 (default): accurate L2 norms - what the reference's device="cuda"
+                                               mode computes; 1 "reference_cpu": every spatial norm as torch's CPU
+                                               kernel returns it (8 fp32 lanes accumulated serially: biased by
+                                               -5e-3 at 67 M elements), which the reference's device="cpu" output
+                                               depends on at the 1e-2 level; ~20 ms per 8192 x 8192 norm */
 } smhip_layer_desc;
 
 typedef struct {

@@ -509,6 +509,7 @@ def synthetic_layer(rows: int, cols: int, k: int, seed: int = 1000, sigmas: Sequ
 
 
 def rel_err(x: torch.Tensor, ref: torch.Tensor) -> float:
+    x, ref = x.detach().cpu(), ref.detach().cpu()
     num = (x.double() - ref.double()).norm().item()
     den = ref.double().norm().item()
     return num / den if den > 0 else num

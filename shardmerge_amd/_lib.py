@@ -45,6 +45,7 @@ class LayerDesc(C.Structure):
         ("cutoff_pct", C.c_double),
         ("t_sum", C.c_double),
         ("b", C.c_double),
+        ("norm_mode", C.c_int),
     ]
 
 

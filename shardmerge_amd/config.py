@@ -15,6 +15,8 @@ reference's shard/config.py:24-126, so existing config files work unchanged.
       t_sum: 1.0
       target_norm_offset: 1.0e-10
       b: 0.1                    # merge_tensors_fft2_slerp's linear-blend threshold (functions.py:164)
+      norm_mode: exact          # exact (accurate norms: the reference's device="cuda" numerics) | reference_cpu
+                                # (torch's biased CPU norm kernel emulated: the reference's device="cpu" output)
       operator: fourier         # fourier (default: what the reference CLI hard-wires, __main__.py:22,67)
                                 # | addition | task_addition (shard/merge/addition.py, taskaddition.py)
 """
@@ -67,6 +69,7 @@ class MergeConfig:
     storage_dir: str = "storage"
     merge_options: Dict[str, float] = field(default_factory=dict)
     operator: str = "fourier"
+    norm_mode: str = "exact"
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -127,13 +130,17 @@ class MergeConfig:
             raise click.BadParameter("finetune_merge must be a list of model URIs")
         raw["finetune_merge"] = [MergeModel(**entry) for entry in raw["finetune_merge"]]
         opts = dict(raw.get("merge_options") or {})
+        norm_mode = opts.pop("norm_mode", "exact")
+        if norm_mode not in ("exact", "reference_cpu"):
+            raise click.BadParameter("merge_options.norm_mode must be 'exact' or 'reference_cpu'")
+        raw["norm_mode"] = norm_mode
         operator = opts.pop("operator", "fourier")
         if operator not in OPERATORS:
             raise click.BadParameter(f"merge_options.operator must be one of {list(OPERATORS)}")
         raw["operator"] = operator
         unknown = set(opts) - set(MERGE_OPTION_DEFAULTS)
         if not isinstance(opts, dict) or unknown:
-            raise click.BadParameter(f"merge_options: unknown keys {sorted(unknown)}; known: {sorted(MERGE_OPTION_DEFAULTS) + ['operator']}")
+            raise click.BadParameter(f"merge_options: unknown keys {sorted(unknown)}; known: {sorted(MERGE_OPTION_DEFAULTS) + ['norm_mode', 'operator']}")
         for key, value in opts.items():
             lo, hi = MERGE_OPTION_RANGES[key]
             if not isinstance(value, (int, float)) or isinstance(value, bool) or not (lo <= float(value) <= hi):

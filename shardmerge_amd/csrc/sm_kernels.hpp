@@ -2084,6 +2084,7 @@ struct Mailbox {
     uint32_t flags[12];         // NaN/Inf flags [0..7] + candidate counters [8..11] (k_publish)
     float thr[4];               // d_thr(0..3)
     BlendConsts consts;
+    float snorm[16];            // k_serial_norm results (norm_mode = reference_cpu)
 };
 struct PublishParams {
     const uint32_t* flags;      // device flags + counters (12 words)
@@ -2435,6 +2436,85 @@ SM_HD void k_delta_norms(Ex& ex, const DeltaNormsParams& p) {
         for (int i = 0; i < NORMS_MAX; ++i) p.partials[(size_t)ex.bid() * NORMS_MAX + i] = tot[i];
     });
 }
+// ---------------------------------------------------------------------------------
+// norm_mode = reference_cpu: ||x||_2 exactly as torch.norm computes it on CPU for a contiguous
+// fp32 tensor - x*x (rounded) accumulated SERIALLY in 8 fp32 lanes (element i goes to lane i % 8),
+// the lanes then added in order, sqrt.  That sum loses low bits once the running sum is large
+// (-7e-4 at 16 M elements, -5e-3 at 67 M: oracle/norm_bias_probe.py), and the reference's
+// pick-the-larger decisions (|ra| / ||a||  vs  |rb| / ||b||) follow the BIASED norms: an
+// implementation with accurate norms differs from the reference's device=cpu output by 2e-2 on
+// the merged delta at 8192^2 (profiles/parity_fullsize.json).  The chain is inherently sequential
+// (n/8 dependent adds per lane: ~20 ms for 8192^2), so this mode is opt-in.
+// One work-group per signal; wave 0's lanes 0..7 hold the accumulators, all waves stage squares
+// of (x - base) through LDS, double-buffered.
+// ---------------------------------------------------------------------------------
+constexpr int SER_CHUNK = 4096;             // elements per staged chunk (512 rows of 8)
+struct SerialNormParams {
+    int k;
+    SigDesc sig[16];
+    size_t n;                               // n % 8 == 0
+    float* out;                             // [k]: the fp32 norm torch would return
+};
+template <class Ex>
+SM_HD void k_serial_norm(Ex& ex, const SerialNormParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    float* buf = ex.lds() + LDS_SCRATCH_FLOATS;          // two buffers of SER_CHUNK floats
+    const int nt = ex.nthreads();
+    const SigDesc sg = p.sig[ex.bid()];
+    const size_t nchunks = (p.n + SER_CHUNK - 1) / SER_CHUNK;
+    auto stage = [&](size_t c, int which) {
+        ex.each(st, [&](int tid, EmptyState&) {
+            float* dst = buf + which * SER_CHUNK;
+            for (int o = tid; o < SER_CHUNK / 8; o += nt) {
+                const size_t i0 = c * SER_CHUNK + (size_t)o * 8;
+                float v[8];
+                if (i0 < p.n) load_sig8(sg, i0, v);
+                else { for (int e = 0; e < 8; ++e) v[e] = 0.f; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[o * 8 + e] = v[e] * v[e];        // rounded product, then a separate add
+            }
+        });
+    };
+    ex.each(st, [&](int, EmptyState& s) { s.red[0] = 0.0; });
+    if (nchunks) stage(0, 0);
+    ex.sync();
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int cur = (int)(c & 1);
+        if (c + 1 < nchunks) stage(c + 1, cur ^ 1);
+        ex.each(st, [&](int tid, EmptyState& s) {
+            if (tid < 8) {
+                float acc = (float)s.red[0];
+                const float* src = buf + cur * SER_CHUNK + tid;
+                const size_t left = p.n - c * SER_CHUNK;
+                const int rows = (int)((left < (size_t)SER_CHUNK ? left : (size_t)SER_CHUNK) / 8);
+                int r = 0;
+                for (; r + 16 <= rows; r += 16) {
+                    float x[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) x[q] = src[(r + q) * 8];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = acc + x[q];
+                }
+                for (; r < rows; ++r) acc = acc + src[r * 8];
+                s.red[0] = (double)acc;
+            }
+        });
+        ex.sync();
+    }
+    // lanes added in order, then the square root (fp32)
+    float* lanes = buf;
+    ex.each(st, [&](int tid, EmptyState& s) { if (tid < 8) lanes[tid] = (float)s.red[0]; });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int q = 0; q < 8; ++q) tot = tot + lanes[q];
+            p.out[ex.bid()] = sqrtf(tot);
+        }
+    });
+}
+
 struct SumNParams { const double* partials; int nparts; double* out; };
 template <class Ex>
 SM_HD void k_sum_partials_n(Ex& ex, const SumNParams& p) {

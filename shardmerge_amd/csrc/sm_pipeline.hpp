@@ -144,6 +144,7 @@ SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
 SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
 SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
 SM_KERNEL_TAG(KAddition, AdditionParams, "addition_merge", k_addition(ex, p))
+SM_KERNEL_TAG(KSerialNorm, SerialNormParams, "serial_norm", k_serial_norm(ex, p))
 SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
 
@@ -1056,6 +1057,22 @@ class Pipeline {
         return true;
     }
 
+    // norm_mode = reference_cpu: the norms as torch's CPU kernel returns them (k_serial_norm).
+    // false: not applicable (n % 8 != 0 or unaligned input) - the caller keeps the exact norms
+    bool run_serial_norms(const SigDesc* sigs, int k, size_t n, double* out) {
+        if (k < 1 || k > 16 || (n % 8) != 0) return false;
+        SerialNormParams q;
+        q.k = k; q.n = n; q.out = mail_->snorm;
+        for (int i = 0; i < 16; ++i) {
+            q.sig[i] = sigs[i < k ? i : 0];
+            if (!aligned16(q.sig[i].x) || !aligned16(q.sig[i].base)) return false;
+        }
+        be.template launch<KSerialNorm>(k, 256, (LDS_SCRATCH_FLOATS + 2 * SER_CHUNK) * 4, q, stream);
+        be.sync(stream);
+        for (int i = 0; i < k; ++i) out[i] = (double)mail_->snorm[i];
+        return true;
+    }
+
     int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
         return with_select_retry([&] { return merge_layer_once(d, out_bf16, delta_out, rep); });
     }
@@ -1075,6 +1092,7 @@ class Pipeline {
         memset(&rp, 0, sizeof rp);
         rp.merged_delta_norm = -1;
 
+        const bool ref_norms = d.norm_mode == 1;       // torch's CPU norm kernel emulated for every spatial norm
         std::vector<Slot> stack(d.k);
         for (int i = 0; i < d.k; ++i) {
             stack[i].sig = SigDesc{d.finetune[i], d.base[i], d.in_dtype, 1.f};
@@ -1120,6 +1138,13 @@ class Pipeline {
                 }
             }
         }
+        if (ref_norms) {
+            SigDesc sg[16];
+            double nr[16];
+            for (int i = 0; i < d.k; ++i) sg[i] = stack[i].sig;
+            if (run_serial_norms(sg, d.k, n, nr))
+                for (int i = 0; i < d.k; ++i) stack[i].norm = nr[i];
+        }
         double mean = 0;
         for (int i = 0; i < d.k; ++i) {
             norms32[i] = (float)stack[i].norm;           // torch.norm of an fp32 tensor is fp32
@@ -1151,7 +1176,7 @@ class Pipeline {
             for (int i = 0; i < 4; ++i) working = working || pidx_[i] == (int)q;
             pool_busy_[q] = working ? 1 : 0;
         }
-        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2;
+        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2 && !ref_norms;   // (needs the spatial intermediate)
         noise_seed_ = 0;                         // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
         int deferred_step = -1;
@@ -1347,6 +1372,7 @@ class Pipeline {
                     if (grid < 0) run_combine(ms, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
                     double nm, dummy;
                     read_norms(grid, nm, dummy);
+                    if (ref_norms) { double nr; if (run_serial_norms(&ms, 1, n, &nr)) nm = nr; }
                     out_norm = nm;
                     Slot s;
                     s.sig = ms; s.weight = (a_w + b_w) / 2.0; s.norm = out_norm;

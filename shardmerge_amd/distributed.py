@@ -363,6 +363,7 @@ async def _merge_block_tensor(merger: FourierMerge, engine, sl: ShardLayer, base
     bases = [await fetch(m.base) for m in models]
     out, report = engine.merge_layer(fts, bases, [m.alpha for m in models], base_view,
                                      target_norm_offset=merger.target_norm_offset, cull_start_pct=merger.cull_start_pct,
-                                     cutoff_pct=merger.cutoff_pct, t_sum=merger.t_sum, b=merger.b, layer_name=sl.layer_name)
+                                     cutoff_pct=merger.cutoff_pct, t_sum=merger.t_sum, b=merger.b, norm_mode=merger.norm_mode,
+                                     layer_name=sl.layer_name)
     merger.last_report = report
     return out

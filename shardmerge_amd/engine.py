@@ -202,7 +202,7 @@ class Engine:
     def merge_layer(self, finetunes: Sequence[torch.Tensor], bases: Sequence[torch.Tensor], alphas: Sequence[float],
                     base_out: torch.Tensor, target_norm_offset: float = 1e-10, cull_start_pct: float = 0.20,
                     cutoff_pct: float = 0.08, t_sum: float = 1.0, want_delta: bool = False,
-                    layer_name: str = "layer", b: float = 0.1):
+                    layer_name: str = "layer", b: float = 0.1, norm_mode: str = "exact"):
         k = len(finetunes)
         if k < 1 or k > _lib.MAX_MODELS:
             raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
@@ -244,6 +244,9 @@ class Engine:
         desc.cutoff_pct = float(cutoff_pct)
         desc.t_sum = float(t_sum)
         desc.b = float(b)
+        if norm_mode not in ("exact", "reference_cpu"):
+            raise ValueError(f"norm_mode {norm_mode!r}: 'exact' or 'reference_cpu'")
+        desc.norm_mode = 1 if norm_mode == "reference_cpu" else 0
         out = torch.empty(bo.shape, dtype=torch.bfloat16, device=self.device)
         delta = torch.empty(bo.shape, dtype=torch.float32, device=self.device) if want_delta else None
         rep = LayerReport()

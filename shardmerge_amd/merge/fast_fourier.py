@@ -41,6 +41,7 @@ class FourierMerge(MergeTensorsBase):
         self.cutoff_pct = 0.08          # fast_fourier.py:239
         self.t_sum = 1.0                # fast_fourier.py:238
         self.b = 0.1                    # functions.py:164 (merge_tensors_fft2_slerp's default, never overridden there)
+        self.norm_mode = getattr(config, "norm_mode", "exact")
         # optional YAML overrides (config.merge_options); absent keys keep the reference's values
         for key, value in (getattr(config, "merge_options", None) or {}).items():
             setattr(self, key, float(value))
@@ -142,7 +143,7 @@ class FourierMerge(MergeTensorsBase):
         out, report = eng.merge_layer(
             fts, bases, [m.alpha for m in models], base_out,
             target_norm_offset=self.target_norm_offset, cull_start_pct=self.cull_start_pct,
-            cutoff_pct=self.cutoff_pct, t_sum=self.t_sum, b=self.b, layer_name=name)
+            cutoff_pct=self.cutoff_pct, t_sum=self.t_sum, b=self.b, norm_mode=self.norm_mode, layer_name=name)
         self.last_report = report
         logger.info(f"Merged {name}: {len(models)} model(s), branches {report.branches}, target norm {report.target_norm:.6g}")
         return out

@@ -386,3 +386,26 @@ def test_linear_blend_branch_with_a_larger_b(engine):
     # and the default keeps the SLERP branch
     out2, rep2 = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base)
     assert rep2.branches == ["slerp"]
+
+
+def test_norm_mode_reference_cpu_reproduces_torch_norm(engine):
+    """merge_options.norm_mode = reference_cpu: every spatial norm is what torch.norm returns on CPU
+    (8 fp32 lanes accumulated serially - biased for large tensors), so the layer follows the
+    reference's device="cpu" decisions: target_norm and the delta norms equal the AS-IS oracle's,
+    bit for bit, and the outputs agree beyond the tie bins."""
+    from oracle import spectral_oracle as so
+    for k, shape in ((2, (512, 1024)), (3, (256, 512))):
+        base, fts = so.synthetic_layer(shape[0], shape[1], k, seed=9100 + k)
+        tr = so.LayerTrace()
+        ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)        # as the reference is
+        out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True, norm_mode="reference_cpu")
+        torch_norms = [float((f.float() - base.float()).norm()) for f in fts]
+        assert rep.delta_norms == torch_norms                       # exactly torch's values
+        assert rep.target_norm == tr.target_norm
+        exact = [float((f.float() - base.float()).double().norm()) for f in fts]
+        assert rep.delta_norms != exact
+        pc.check_layer_steps(rep, tr, out.numel())
+        if k == 2:
+            assert pc.spectral_residual(delta.cpu(), tr.merged_delta)[1] < 2e-5
+    with pytest.raises(ValueError):
+        engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, norm_mode="fast")
