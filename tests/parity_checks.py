@@ -171,10 +171,14 @@ def step_intermediate_inputs(tr, k):
     return out
 
 
-def check_layer_steps(rep, tr, numel, reported_fields=True):
+def check_layer_steps(rep, tr, numel, reported_fields=True, biased_slerp_norms=False):
     """Every pairing step of the HIP path's report against the oracle's trace.
     reported_fields=False skips t and the cull fraction (values the library merely reports
-    back) so that a test can show the MEASURED quantities alone catch a slip."""
+    back) so that a test can show the MEASURED quantities alone catch a slip.
+    biased_slerp_norms=True: `tr` is the AS-IS oracle at a size where torch's CPU norm is visibly
+    biased (>= 16 M elements); norm_mode = reference_cpu reproduces its SPATIAL norms (the cutoff
+    threshold then matches tightly) but not the norms of the gathered slerp-class vectors, so the
+    cosine and what follows from it (the cull threshold) agree to the size of that bias only."""
     assert rep.branches == tr.branches
     assert [(s[0], s[1]) for s in rep.steps] == tr.pairs
     k = len(rep.delta_norms)
@@ -189,9 +193,10 @@ def check_layer_steps(rep, tr, numel, reported_fields=True):
         if n_inter[i] == 0:
             first_cut = bt.cutoff_threshold if first_cut is None else first_cut
             assert abs(info.cutoff_threshold - bt.cutoff_threshold) <= 1e-5 * bt.cutoff_threshold + 1e-30, f"step {i} cutoff"
-            assert abs(info.cull_threshold - bt.cull_threshold) <= 5e-5 * bt.cull_threshold + 1e-30, f"step {i} cull"
+            loose = 100.0 if biased_slerp_norms else 1.0
+            assert abs(info.cull_threshold - bt.cull_threshold) <= loose * 5e-5 * bt.cull_threshold + 1e-30, f"step {i} cull"
             assert abs(info.n_slerp - bt.n_slerp) <= 4 + 1e-4 * bt.n_slerp, f"step {i} n_slerp"
-            assert abs(info.dot - bt.dot) <= 1e-4, f"step {i} dot"
+            assert abs(info.dot - bt.dot) <= loose * 1e-4, f"step {i} dot"
         else:
             if first_cut:
                 assert info.cutoff_threshold < 1e-3 * first_cut and bt.cutoff_threshold < 1e-3 * first_cut, \

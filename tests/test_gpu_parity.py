@@ -443,7 +443,7 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     assert rec["as_is"]["delta_rel_err"] < 1e-3 + 1.5 * rec["reference_self_shift"]["delta"]
     # norm_mode = reference_cpu: BASELINE's tolerance (1e-3 relative, bf16 output) against the
     # reference's device="cpu" output AS IT IS, and the stricter delta-level bar of SURVEY 8(d)
-    pc.check_layer_steps(rep_r, tr, out.numel())
+    pc.check_layer_steps(rep_r, tr, out.numel(), biased_slerp_norms=True)
     assert rep_r.target_norm == tr.target_norm
     assert rec["as_is_with_norm_mode_reference_cpu"]["out_rel_err"] < 1e-3
     assert rec["as_is_with_norm_mode_reference_cpu"]["delta_rel_err"] < 2e-3
