@@ -524,6 +524,7 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
             constexpr int QB = SM_F1Q_QB;
             static_for<0, NQ / QB>([&](auto h_c) {
                 constexpr int Q0 = decltype(h_c)::value * QB, Q1 = Q0 + QB;
+                SM_SCHED_FENCE();                  // one batch's loads and decode at a time
 #pragma unroll
                 for (int q = Q0; q < Q1; ++q) ra[q] = pa[offq(q) / 8];
 #pragma unroll
@@ -630,10 +631,6 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
         const int g = tid / T, t = tid % T;
         // twiddles W_R^{n2 k1}: slot A is column element n2A, slot B n2B (they differ in row-pair mode)
         const int n2A = p.rowpair ? 2 * unit : unit, n2B = p.rowpair ? 2 * unit + 1 : unit;
-        cf2 wA[4], wB[4];
-        wA[0].x = 1.f; wA[0].y = 0.f; wB[0] = wA[0];
-#pragma unroll
-        for (int k1 = 1; k1 < 4; ++k1) { wA[k1] = p.twR[(size_t)n2A * k1]; wB[k1] = p.twR[(size_t)n2B * k1]; }
         const bool has_b = p.b.x != nullptr;
         cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * p.pitch4 * p.ilv + (unit % p.ilv);
         const size_t slabstride = p.slab_elems;                  // slab-major: [k1][unit][bin]
@@ -646,7 +643,11 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
             Dft<4>::run(br, bi);
 #pragma unroll
             for (int k1 = 0; k1 < 4; ++k1) {
-                if (k1) { cmul(ar[k1], ai[k1], wA[k1].x, wA[k1].y); cmul(br[k1], bi[k1], wB[k1].x, wB[k1].y); }
+                if (k1) {
+                    // work-group-uniform addresses: the twiddles come through the scalar cache, not VGPRs
+                    const cf2 wa = p.twR[(size_t)n2A * k1], wb = p.twR[(size_t)n2B * k1];
+                    cmul(ar[k1], ai[k1], wa.x, wa.y); cmul(br[k1], bi[k1], wb.x, wb.y);
+                }
                 cf4 v = {ar[k1], ai[k1], br[k1], bi[k1]};
                 rowp[(size_t)k * p.ilv + k1 * slabstride] = v;
             }
