@@ -98,23 +98,23 @@ KERNEL_ALG_BYTES = {
 def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
     """Algorithmic bytes per tensor element summed over ALL launches of kernel `name` in one
     K-way layer merge as THIS implementation runs it (DESIGN.md section 5): K-1 pair merges;
-    floor(K/2) of them take two raw bf16 deltas; every non-final result stays in the spectral
-    domain (no inverse / forward transform between rounds: spec_norm + spec_rescale instead);
-    a raw delta that meets an intermediate (odd K) is transformed alone (row-pair F1 + F2S)."""
+    K = 2: one fused two-signal pair.  K >= 3: every delta's rows are transformed alone first (row
+    pairs; the norms come with it), column passes per signal once the pairing is known, every
+    non-final result stays in the spectral domain (spec_norm + spec_rescale, no transforms)."""
     pairs = max(k - 1, 1)
-    raw = k // 2                                 # pairs whose two inputs are raw bf16 deltas
-    singles = (k - 2 * raw) if k >= 3 else 0     # raw deltas transformed alone
-    inter = pairs - 1                            # spectral intermediates produced and consumed
     per = KERNEL_ALG_BYTES.get(name, 0.0)
-    table = {
-        "f1_rows_fwd": raw * 14.0 + singles * 8.0,     # pair: 6n in + 8n out; alone: 4n in + 4n out
-        "f2_cols_fwd": raw * 14.0,
-        "f2s_cols_fwd1": singles * 8.0,                # 4n in + Re, Im out
-        "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
-        "spec_norm": inter * 4.0,                      # Re R + Im a
-        "spec_rescale": inter * 4.0,                   # role b: Re in, Re out (role a: 8n)
-        "select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs,
-    }
+    if k >= 3:
+        inter = pairs - 1                        # spectral intermediates produced and consumed
+        table = {
+            "f1_rows_fwd": k * 8.0,                        # every delta alone (row pairs): 4n in + 4n out, norms included
+            "f2s_cols_fwd1": k * 7.0,                      # 4n in + Re, Im out (role a) or Re out (role b)
+            "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
+            "spec_norm": inter * 4.0,                      # Re R + Im a
+            "spec_rescale": inter * 4.0,                   # role b: Re in, Re out (role a: 8n)
+            "select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs,
+        }
+    else:
+        table = {"select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs}
     if k >= 2 and name in table:
         return table[name]
     return per * pairs

@@ -21,6 +21,14 @@
 #define SM_HD inline
 #endif
 #define SM_CONST static constexpr
+// make an integer opaque to the optimizer at this point: values derived from it cannot be hoisted
+// above it, i.e. they are recomputed where they are used instead of living (or being spilled)
+// across the whole kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SM_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define SM_OPAQUE(x) ((void)0)
+#endif
 // keep the instruction scheduler from interleaving independent butterflies: one
 // butterfly's temporaries die before the next one's are born (register pressure)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SM_NO_SCHED_BARRIER)

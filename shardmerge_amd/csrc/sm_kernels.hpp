@@ -479,6 +479,9 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
 #ifndef SM_F1Q_QB
 #define SM_F1Q_QB 1          // 16-byte loads per operand in flight per batch (register budget: 128)
 #endif
+#ifndef SM_F1Q_PREFETCH_B
+#define SM_F1Q_PREFETCH_B 1     // issue the second operand's loads before the first exchange (measured: -2..5 %)
+#endif
 #ifndef SM_F1Q_PACK
 #define SM_F1Q_PACK true
 #endif
@@ -486,196 +489,200 @@ template <class P> constexpr bool f1q_eligible() {
     if constexpr (P::is_static) return 4 * P::T <= 1024 && (P::N / P::T) % 2 == 0 && P::N % 8 == 0; else return false;
 }
 
+struct F1QState {
+    float xr[EREG];
+    float xi[EREG];
+    double red[4];
+    u32x4 rb[EMAX / 8], rbb[EMAX / 8];      // the second operand's raw 16-bit loads, in flight during the first exchange
+};
+
 template <class P, class Ex>
 SM_HD void k_f1q(Ex& ex, const F1Params& p) {
     if constexpr (!f1q_eligible<P>()) { return; } else {
-    typename Ex::template State<FftState> st;
+    typename Ex::template State<F1QState> st;
     ex.init(st);
     float* lds = ex.lds() + LDS_SCRATCH_FLOATS;
     const FftPlanDev& pl = p.plan;
     constexpr int T = P::T, C = P::N, LF = P::lds_floats;
     constexpr int E2 = C / T / 2;                  // bins k = t + u*T, u < E2, plus the Nyquist bin (t = 0, u = E2)
     constexpr int NJ = (E2 + 3) / 4;               // main bins per thread: u = 4*jj + g
+    constexpr int NQ = EMAX / 8;
     static_assert(NJ * 8 + 4 <= EREG, "register slots");
     const int bid = (p.ilv > 1) ? xcd_remap(ex.bid(), p.ilv) : ex.bid();
     const int pbid = ex.bid();
     const int unit = bid;                           // n2 (or the row-pair index m2)
     const bool live = unit < p.R2;
+    const bool bits16 = p.a.dtype != DT_F32 && p.b.dtype != DT_F32;
+    const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
+    // twiddles W_R^{n2 k1}: slot A is column element n2A, slot B n2B (they differ in row-pair mode)
+    const int n2A = p.rowpair ? 2 * unit : unit, n2B = p.rowpair ? 2 * unit + 1 : unit;
+    cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * p.pitch4 * p.ilv + (unit % p.ilv);
+    const size_t slabstride = p.slab_elems;                      // slab-major: [k1][unit][bin]
 
-    ex.each(st, [&](int tid, FftState& s) {
-        const int g = tid / T, t = tid % T;
-        const int row = unit + g * p.R2;
-        const bool valid = live;
-        double sa = 0.0, sb = 0.0;
-        constexpr int NQ = EMAX / 8;
-        // (offsets are recomputed where they are used: every register counts at 128 per thread)
-        const size_t rowoff = (size_t)row * p.row_stride;
-        auto okq = [&](int q) { return valid && 8 * (t + q * T) < C; };
-        auto offq = [&](int q) { return okq(q) ? rowoff + 8 * (t + q * T) : (size_t)0; };
-        if (p.a.dtype != DT_F32 && p.b.dtype != DT_F32) {
-            // 16-bit inputs: two batches of 16-byte loads (the 128-VGPR budget of a 1024-thread
-            // work-group), issued back to back, clamped instead of branched around
-            u32x4 ra[NQ], rab[NQ], rb[NQ], rbb[NQ];     // (only one batch of them is live at a time)
-            const bool has_ab = p.a.base != nullptr, has_b = p.b.x != nullptr, has_bb = has_b && p.b.base != nullptr;
-            const u32x4* pa = (const u32x4*)p.a.x;
-            const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
-            const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
-            const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
-            constexpr int QB = SM_F1Q_QB;
-            static_for<0, NQ / QB>([&](auto h_c) {
-                constexpr int Q0 = decltype(h_c)::value * QB, Q1 = Q0 + QB;
-                SM_SCHED_FENCE();                  // one batch's loads and decode at a time
+    ex.each(st, [&](int, F1QState& s) { s.red[0] = 0.0; s.red[1] = 0.0; });
+
+    // Register budget: a 1024-thread work-group has 128 VGPRs per thread.  The operands are
+    // therefore loaded one at a time, straight into the first LDS scatter (a in the pass of the
+    // real component, b in the pass of the imaginary one; b's raw loads are issued before a's
+    // exchange and land during it), and the last gather of the imaginary component does the
+    // cross-row butterfly and the stores bin by bin instead of parking 36 more values.
+    wg_fft<P, SM_F1Q_PACK>(ex, st, pl, lds,
+        [&](int tid, F1QState& s, auto comp_c) {
+            constexpr int comp = decltype(comp_c)::value;          // natural scatter = operand load
+            int tid_ = tid;
+            SM_OPAQUE(tid_);
+            const int g = tid_ / T, t = tid_ % T;
+            float* l = lds + g * LF;
+            const size_t rowoff = (size_t)(unit + g * p.R2) * p.row_stride;
+            auto okq = [&](int q) { return live && 8 * (t + q * T) < C; };
+            auto offq = [&](int q) { return okq(q) ? rowoff + 8 * (t + q * T) : (size_t)0; };
+            double ss = 0.0;
+            if (bits16) {
+                const u32x4* pa = (const u32x4*)p.a.x;
+                if (comp == 0) {
+                    const u32x4* pab = has_ab ? (const u32x4*)p.a.base : pa;
+                    u32x4 ra[NQ], rab[NQ];
 #pragma unroll
-                for (int q = Q0; q < Q1; ++q) ra[q] = pa[offq(q) / 8];
+                    for (int q = 0; q < NQ; ++q) ra[q] = pa[offq(q) / 8];
 #pragma unroll
-                for (int q = Q0; q < Q1; ++q) rab[q] = pab[offq(q) / 8];
+                    for (int q = 0; q < NQ; ++q) rab[q] = pab[offq(q) / 8];
+#if SM_F1Q_PREFETCH_B
+                    const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
+                    const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
 #pragma unroll
-                for (int q = Q0; q < Q1; ++q) rb[q] = pb[offq(q) / 8];
+                    for (int q = 0; q < NQ; ++q) s.rb[q] = pb[offq(q) / 8];
 #pragma unroll
-                for (int q = Q0; q < Q1; ++q) rbb[q] = pbb[offq(q) / 8];
+                    for (int q = 0; q < NQ; ++q) s.rbb[q] = pbb[offq(q) / 8];
+#endif
 #pragma unroll
-                for (int q = Q0; q < Q1; ++q) {
-                    float va[8], vb[8], ba[8], bb[8];
-                    decode16x8(ra[q], p.a.dtype, va);
-                    decode16x8(rab[q], p.a.dtype, ba);
-                    decode16x8(rb[q], p.b.dtype, vb);
-                    decode16x8(rbb[q], p.b.dtype, bb);
-                    float qa = 0.f, qb = 0.f;
+                    for (int q = 0; q < NQ; ++q) {
+                        float va[8], ba[8];
+                        decode16x8(ra[q], p.a.dtype, va);
+                        decode16x8(rab[q], p.a.dtype, ba);
+                        const int n0 = 8 * (t + q * T);
+                        float qa = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float xa = (va[c] - (has_ab ? ba[c] : 0.f)) * p.a.prescale;
-                        float xb = has_b ? (vb[c] - (has_bb ? bb[c] : 0.f)) * p.b.prescale : 0.f;
-                        if (!okq(q)) { xa = 0.f; xb = 0.f; }
-                        s.xr[q * 8 + c] = xa; s.xi[q * 8 + c] = xb;
-                        qa += xa * xa; qb += xb * xb;
+                        for (int c = 0; c < 8; ++c) {
+                            float xa = (va[c] - (has_ab ? ba[c] : 0.f)) * p.a.prescale;
+                            if (!okq(q)) xa = 0.f;
+                            if (n0 < C) l[lpad(n0 + c)] = xa;
+                            qa += xa * xa;
+                        }
+                        ss += qa;
                     }
-                    sa += qa; sb += qb;
-                }
-            });
-        } else {
-            auto load_signal = [&](const SigDesc& sg, float* dst, double& ss) {
-                if (!sg.x) {
+                } else {
+#if !SM_F1Q_PREFETCH_B
+                    const u32x4* pb = has_b ? (const u32x4*)p.b.x : pa;
+                    const u32x4* pbb = has_bb ? (const u32x4*)p.b.base : pa;
 #pragma unroll
-                    for (int i = 0; i < 8 * NQ; ++i) dst[i] = 0.f;
-                    return;
+                    for (int q = 0; q < NQ; ++q) s.rb[q] = pb[offq(q) / 8];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) s.rbb[q] = pbb[offq(q) / 8];
+#endif
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float vb[8], bb[8];
+                        decode16x8(s.rb[q], p.b.dtype, vb);
+                        decode16x8(s.rbb[q], p.b.dtype, bb);
+                        const int n0 = 8 * (t + q * T);
+                        float qb = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float xb = has_b ? (vb[c] - (has_bb ? bb[c] : 0.f)) * p.b.prescale : 0.f;
+                            if (!okq(q)) xb = 0.f;
+                            if (n0 < C) l[lpad(n0 + c)] = xb;
+                            qb += xb * xb;
+                        }
+                        ss += qb;
+                    }
                 }
+            } else {
+                const SigDesc& sg = comp == 0 ? p.a : p.b;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     float v[8];
-                    load_sig8(sg, offq(q), v);
+                    if (sg.x) load_sig8(sg, offq(q), v);
+                    else { for (int c = 0; c < 8; ++c) v[c] = 0.f; }
+                    const int n0 = 8 * (t + q * T);
                     float ps = 0.f;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const float x = okq(q) ? v[c] : 0.f;
-                        dst[q * 8 + c] = x;
+                        if (n0 < C) l[lpad(n0 + c)] = x;
                         ps += x * x;
                     }
                     ss += ps;
                 }
-            };
-            load_signal(p.a, s.xr, sa);
-            load_signal(p.b, s.xi, sb);
-        }
-        s.red[0] = sa; s.red[1] = sb;
-    });
-    ex.template block_sum<2>(st, [&](const double* tot) {
-        p.partials[2 * (size_t)pbid] = tot[0];
-        p.partials[2 * (size_t)pbid + 1] = tot[1];
-    });
-
-    wg_fft<P, SM_F1Q_PACK>(ex, st, pl, lds,
-        [&](int tid, FftState& s, auto comp_c) {
-            constexpr int comp = decltype(comp_c)::value;          // natural scatter
-            const int g = tid / T, t = tid % T;
-            float* l = lds + g * LF;
-            const float* x = comp_of<comp>(s);
-#pragma unroll
-            for (int q = 0; q < EMAX / 8; ++q) {
-                const int n0 = 8 * (t + q * T);
-                if (n0 < C) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) l[lpad(n0 + c)] = x[q * 8 + c];
-                }
             }
+            s.red[comp] += ss;
         },
-        [&](int tid, FftState& s, auto comp_c) {
+        [&](int tid, F1QState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
-            // every thread takes a quarter of the bins, of ALL FOUR rows: slot (jj*4 + g')*2 + {0, 1}
-            const int g = tid / T, t = tid % T;
-            float* o = comp_of<comp>(s);
+            // every thread takes a quarter of the bins, of ALL FOUR rows.  The real component's
+            // pass parks (A.re, B.im) in xr[(jj*4 + g')*2 + {0,1}]; the imaginary component's
+            // pass gets (A.im, B.re), does the radix-4 butterfly over the rows and stores.
+            int tid_ = tid;
+            SM_OPAQUE(tid_);                           // addresses below are recomputed here, not carried from the top
+            const int g = tid_ / T, t = tid_ % T;
+            auto emit = [&](int k, const float* are, const float* aim, const float* bre, const float* bim) {
+                SM_SCHED_FENCE();                      // one bin's butterflies at a time (register pressure)
+                float ar[4], ai[4], br[4], bi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ar[q] = are[q]; ai[q] = aim[q]; br[q] = has_b ? bre[q] : 0.f; bi[q] = has_b ? bim[q] : 0.f; }
+                Dft<4>::run(ar, ai);
+                Dft<4>::run(br, bi);
+#pragma unroll
+                for (int k1 = 0; k1 < 4; ++k1) {
+                    if (k1) {
+                        // work-group-uniform addresses: the twiddles come through the scalar cache, not VGPRs
+                        const cf2 wa = p.twR[(size_t)n2A * k1], wb = p.twR[(size_t)n2B * k1];
+                        cmul(ar[k1], ai[k1], wa.x, wa.y); cmul(br[k1], bi[k1], wb.x, wb.y);
+                    }
+                    cf4 v = {ar[k1], ai[k1], br[k1], bi[k1]};
+                    if (live) rowp[(size_t)k * p.ilv + k1 * slabstride] = v;
+                }
+                SM_SCHED_FENCE();
+            };
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
                 const int u = 4 * jj + g;
                 if (u < E2) {
                     const int k = t + u * T;
                     const int k2 = (k == 0) ? 0 : C - k;
+                    float aim[4], bre[4];
 #pragma unroll
                     for (int gp = 0; gp < 4; ++gp) {
                         const float* l = lds + gp * LF;
                         const float v1 = l[lpad(k)], v2 = l[lpad(k2)];
                         const int sl = (jj * 4 + gp) * 2;
-                        if (comp == 0) { o[sl] = 0.5f * (v1 + v2); o[sl + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
-                        else           { o[sl] = 0.5f * (v1 - v2); o[sl + 1] = 0.5f * (v1 + v2); }   // A.im, B.re
+                        if (comp == 0) { s.xr[sl] = 0.5f * (v1 + v2); s.xr[sl + 1] = 0.5f * (v2 - v1); }   // A.re, B.im
+                        else           { aim[gp] = 0.5f * (v1 - v2); bre[gp] = 0.5f * (v1 + v2); }           // A.im, B.re
+                    }
+                    if (comp == 1) {
+                        float are[4], bim[4];
+#pragma unroll
+                        for (int gp = 0; gp < 4; ++gp) { are[gp] = s.xr[(jj * 4 + gp) * 2]; bim[gp] = s.xr[(jj * 4 + gp) * 2 + 1]; }
+                        emit(k, are, aim, bre, bim);
                     }
                 }
             }
             if (tid == 0) {                                  // the Nyquist bin k = C/2: its own twin
+                if (comp == 0) {
 #pragma unroll
-                for (int gp = 0; gp < 4; ++gp) o[NJ * 8 + gp] = lds[gp * LF + lpad(C / 2)];
+                    for (int gp = 0; gp < 4; ++gp) s.xr[NJ * 8 + gp] = lds[gp * LF + lpad(C / 2)];
+                } else {
+                    float are[4], aim[4] = {0.f, 0.f, 0.f, 0.f}, bre[4], bim[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int gp = 0; gp < 4; ++gp) { are[gp] = s.xr[NJ * 8 + gp]; bre[gp] = lds[gp * LF + lpad(C / 2)]; }
+                    emit(C / 2, are, aim, bre, bim);
+                }
             }
         });
 
-#ifndef SM_DBG_NOSTORE
-    ex.each(st, [&](int tid, FftState& s) {
-        if (!live) return;
-        const int g = tid / T, t = tid % T;
-        // twiddles W_R^{n2 k1}: slot A is column element n2A, slot B n2B (they differ in row-pair mode)
-        const int n2A = p.rowpair ? 2 * unit : unit, n2B = p.rowpair ? 2 * unit + 1 : unit;
-        const bool has_b = p.b.x != nullptr;
-        cf4* const rowp = p.t1 + (size_t)(unit / p.ilv) * p.pitch4 * p.ilv + (unit % p.ilv);
-        const size_t slabstride = p.slab_elems;                  // slab-major: [k1][unit][bin]
-        auto emit = [&](int k, const float* are, const float* aim, const float* bre, const float* bim) {
-            SM_SCHED_FENCE();                      // one bin's butterflies at a time (register pressure)
-            float ar[4], ai[4], br[4], bi[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { ar[q] = are[q]; ai[q] = aim[q]; br[q] = has_b ? bre[q] : 0.f; bi[q] = has_b ? bim[q] : 0.f; }
-            Dft<4>::run(ar, ai);
-            Dft<4>::run(br, bi);
-#pragma unroll
-            for (int k1 = 0; k1 < 4; ++k1) {
-                if (k1) {
-                    // work-group-uniform addresses: the twiddles come through the scalar cache, not VGPRs
-                    const cf2 wa = p.twR[(size_t)n2A * k1], wb = p.twR[(size_t)n2B * k1];
-                    cmul(ar[k1], ai[k1], wa.x, wa.y); cmul(br[k1], bi[k1], wb.x, wb.y);
-                }
-                cf4 v = {ar[k1], ai[k1], br[k1], bi[k1]};
-                rowp[(size_t)k * p.ilv + k1 * slabstride] = v;
-            }
-            SM_SCHED_FENCE();
-        };
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const int u = 4 * jj + g;
-            if (u < E2) {
-                float are[4], aim[4], bre[4], bim[4];
-#pragma unroll
-                for (int gp = 0; gp < 4; ++gp) {
-                    const int sl = (jj * 4 + gp) * 2;
-                    are[gp] = s.xr[sl]; bim[gp] = s.xr[sl + 1]; aim[gp] = s.xi[sl]; bre[gp] = s.xi[sl + 1];
-                }
-                emit(t + u * T, are, aim, bre, bim);
-            }
-        }
-        if (tid == 0) {
-            float are[4], aim[4] = {0.f, 0.f, 0.f, 0.f}, bre[4], bim[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int gp = 0; gp < 4; ++gp) { are[gp] = s.xr[NJ * 8 + gp]; bre[gp] = s.xi[NJ * 8 + gp]; }
-            emit(C / 2, are, aim, bre, bim);
-        }
+    ex.template block_sum<2>(st, [&](const double* tot) {
+        p.partials[2 * (size_t)pbid] = tot[0];
+        p.partials[2 * (size_t)pbid + 1] = tot[1];
     });
-#else
-    ex.each(st, [&](int tid, FftState& s) { float acc = 0.f; for (int q = 0; q < 36; ++q) acc += s.xr[q] + s.xi[q]; p.t1[tid].x = acc; });
-#endif
     }
 }
 

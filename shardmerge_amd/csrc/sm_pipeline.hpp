@@ -226,6 +226,7 @@ class Pipeline {
         for (Buffer& b : pool_) if (b.p) be.free(b.p);
         if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
+        for (Buffer& b : rowspec_) if (b.p) be.free(b.p);
     }
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
@@ -279,6 +280,7 @@ class Pipeline {
     size_t workspace_bytes() const {
         size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
         for (const Buffer& b : inter_) t += b.cap;
+        for (const Buffer& b : rowspec_) t += b.cap;
         for (const Buffer& b : pool_) t += b.cap;
         return t;
     }
@@ -473,8 +475,10 @@ class Pipeline {
     // rows (2m, 2m+1) of ONE signal as the two operands of the two-for-one row transform:
     // T1[m][k] = (spectrum of row 2m, spectrum of row 2m+1).  R must be even.
     // float4 per k1 slab of the folded T1 (R/4 rows of one real pitch)
-    static size_t fold_slab_elems(const Geo& g) { return round_up((size_t)g.R / 4, 8) * (size_t)g.pitch4; }
-    int run_f1_rowpairs(const Geo& g, const SigDesc& sig) {
+    static size_t fold_slab_elems(const Geo& g, bool rowpair = false) {
+        return round_up((size_t)g.R / (rowpair ? 8 : 4), 8) * (size_t)g.pitch4;
+    }
+    int run_f1_rowpairs(const Geo& g, const SigDesc& sig, void* t1buf = nullptr, double* partials = nullptr, int* grid_out = nullptr) {
         F1Params p;
         int rc = get_plan(g.C, p.plan);
         if (rc) return rc;
@@ -485,9 +489,9 @@ class Pipeline {
         p.nb = std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)2 * g.C;
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
-        p.t1 = (cf4*)t1_.p;
-        p.partials = d_part();
-        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g);
+        p.t1 = (cf4*)(t1buf ? t1buf : t1_.p);
+        p.partials = partials ? partials : d_part();
+        p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g, true);
         if (g.fold == 4) {
             if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
             FftPlanDev colp;
@@ -495,22 +499,24 @@ class Pipeline {
             p.R2 = g.R / 8; p.rowpair = 1; p.twR = colp.tw; p.ilv = 1; p.nb = 4;      // units = row pairs
             const int gridq = (int)round_up((size_t)p.R2, 8);
             launch_fft<KF1Q>(p.plan, gridq, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
+            if (grid_out) *grid_out = gridq;
             return SMHIP_OK;
         }
         const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8);
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
         launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+        if (grid_out) *grid_out = grid;
         return SMHIP_OK;
     }
-    int run_f2s(const Geo& g, bool role_a, float scale, bool hist) {
+    int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr) {
         F2SParams p;
         const int Rt = g.R / g.fold;                 // transform length (R2 on the folded path)
         int rc = get_plan(Rt, p.plan);
         if (rc) return rc;
-        p.t1 = (const cf4*)t1_.p; p.pitch4 = g.pitch4 * g.fold; p.R = Rt; p.C = g.C;
+        p.t1 = (const cf4*)(t1buf ? t1buf : t1_.p); p.pitch4 = g.pitch4 * g.fold; p.R = Rt; p.C = g.C;
         p.Cb = g.fold == 4 ? 4 * g.pitch4 : g.C / 2 + 1;
-        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R; p.slab_elems = fold_slab_elems(g);
+        p.slab = g.pitch4; p.Cb_real = g.C / 2 + 1; p.Rfull = g.R; p.slab_elems = fold_slab_elems(g, true);
         p.role_a = role_a ? 1 : 0; p.scale = scale;
         p.re = plane(g, role_a ? P_REA : P_REB); p.im = plane(g, P_IMA);
         p.hist = hist ? d_hist() : nullptr;
@@ -1008,6 +1014,7 @@ class Pipeline {
         float thr = 0.f;                // cull threshold (0: none)
         double spec_scale = 1.0;        // 1 / sqrt(sum |R_culled|^2 / n): brings the spectrum to unit spatial norm
         double post = 1.0;              // spatial values = post * ifft(R)   (target_norm)
+        int rows_id = -1;               // >= 0: rowspec_[rows_id] holds this raw delta's row spectra (row-pair layout)
     };
     // spectral -> spatial fp32 (the branches that need spatial inputs: add, Arithmetic-FFT, early-out)
     int materialise(const Geo& g, Slot& s, std::vector<char>& inter_busy) {
@@ -1073,6 +1080,30 @@ class Pipeline {
         return true;
     }
 
+    // row spectra of every raw delta (row-pair F1 each) + their norms with ONE sync
+    int rows_first(const Geo& g, std::vector<Slot>& stack) {
+        const int k = (int)stack.size();
+        if ((int)rowspec_.size() < k) rowspec_.resize(k);
+        const size_t bytes = round_up((size_t)g.R, 8) / 2 * (size_t)g.pitch4 * sizeof(cf4) + 4096;
+        int rc;
+        std::vector<int> grids(k);
+        size_t poff = 0;
+        for (int i = 0; i < k; ++i) {
+            if ((rc = ensure(rowspec_[i], bytes))) return rc;
+            if ((rc = run_f1_rowpairs(g, stack[i].sig, rowspec_[i].p, d_part() + poff, &grids[i]))) return rc;
+            SumPartialsParams sp;
+            sp.partials = d_part() + poff; sp.nparts = grids[i]; sp.out = mail_->norm2 + 2 * i;
+            be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
+            poff += 2 * (size_t)grids[i];
+        }
+        be.sync(stream);
+        for (int i = 0; i < k; ++i) {
+            stack[i].norm = std::sqrt(mail_->norm2[2 * i] + mail_->norm2[2 * i + 1]);      // even rows + odd rows
+            stack[i].rows_id = i;
+        }
+        return SMHIP_OK;
+    }
+
     int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
         return with_select_retry([&] { return merge_layer_once(d, out_bf16, delta_out, rep); });
     }
@@ -1093,6 +1124,7 @@ class Pipeline {
         rp.merged_delta_norm = -1;
 
         const bool ref_norms = d.norm_mode == 1;       // torch's CPU norm kernel emulated for every spatial norm
+        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2 && !ref_norms;   // (ref_norms needs the spatial intermediate)
         std::vector<Slot> stack(d.k);
         for (int i = 0; i < d.k; ++i) {
             stack[i].sig = SigDesc{d.finetune[i], d.base[i], d.in_dtype, 1.f};
@@ -1124,6 +1156,11 @@ class Pipeline {
             read_norms(f1_grid, na, nb);
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
+        } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(R / 2 + 8) <= PART_DOUBLES &&
+                   rows_first(g, stack) == SMHIP_OK) {
+            // K >= 3: every delta's ROWS are transformed up front, one signal at a time (row pairs);
+            // the norms come with it (no separate pass over the inputs), and whichever deltas the
+            // pairing puts together only need their column passes afterwards
         } else {
             if (!run_delta_norms(d, n, stack)) {
                 SigDesc none{nullptr, nullptr, DT_F32, 1.f};
@@ -1176,7 +1213,6 @@ class Pipeline {
             for (int i = 0; i < 4; ++i) working = working || pidx_[i] == (int)q;
             pool_busy_[q] = working ? 1 : 0;
         }
-        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2 && !ref_norms;   // (needs the spatial intermediate)
         noise_seed_ = 0;                         // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
         int deferred_step = -1;
@@ -1286,7 +1322,8 @@ class Pipeline {
                             run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
                         }
                     } else {
-                        const bool any_spec = stack[x].spectral || stack[y].spectral;
+                        const bool any_spec = stack[x].spectral || stack[y].spectral ||
+                                              (stack[x].rows_id >= 0 && stack[y].rows_id >= 0);
                         if (!any_spec) {
                             if (!(f1_ready && d.k == 2)) {
                                 int grid;
@@ -1307,6 +1344,9 @@ class Pipeline {
                                 if (in.spectral) {
                                     run_spec_rescale(g, (const float*)pool_[in.re_id].p, (const float*)pool_[in.im_id].p, in.thr,
                                                      (float)in.spec_scale, role_a, d.cutoff_pct > 0);
+                                } else if (in.rows_id >= 0) {
+                                    if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0,
+                                                      rowspec_[in.rows_id].p))) return rc;
                                 } else {
                                     if ((rc = run_f1_rowpairs(g, in.sig))) return rc;
                                     if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0))) return rc;
@@ -1522,6 +1562,7 @@ class Pipeline {
     bool flags_clean_ = false;
     Mailbox* mail_ = nullptr;
     std::vector<Buffer> inter_;
+    std::vector<Buffer> rowspec_;          // K >= 3: row spectra of the raw deltas (rows_first)
     std::vector<double> host_part_;
 };
 

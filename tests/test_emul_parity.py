@@ -303,7 +303,10 @@ def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(en
     assert tab_m["i2_rows_inv"][0] == n_pairs and "spec_rescale" not in tab_m
     assert tab_s["i2_rows_inv"][0] == 1 and tab_s["i1_cols_inv"][0] == 1          # only the final inverse
     assert tab_s["spec_norm"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
-    assert tab_s["f1_rows_fwd"][0] == (k + 1) // 2                                 # K = 4: two pairs of raw deltas, then none
+    # every raw delta's rows are transformed once, alone (the norms come with it: no delta_norms pass),
+    # and its column pass runs when the pairing has placed it
+    assert tab_s["f1_rows_fwd"][0] == k and tab_s["f2s_cols_fwd1"][0] == k
+    assert "f2_cols_fwd" not in tab_s and "delta_norms" not in tab_s
     assert rep_s.branches == rep_m.branches
     floor = golden.manifest["layer_self_floor"][cid]
     from oracle import spectral_oracle as so
