@@ -107,6 +107,7 @@ def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
         inter = pairs - 1                        # spectral intermediates produced and consumed
         table = {
             "f1_rows_fwd": k * 8.0,                        # every delta alone (row pairs): 4n in + 4n out, norms included
+            "f2_cols_fwd": 0.0,                            # (the fused two-signal column pass is K = 2's)
             "f2s_cols_fwd1": k * 7.0,                      # 4n in + Re, Im out (role a) or Re out (role b)
             "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
             "spec_norm": inter * 4.0,                      # Re R + Im a
