@@ -223,6 +223,9 @@ template <class P> constexpr bool f1_full_batch() {
 #ifndef SM_ROW_PACK_MAX_T
 #define SM_ROW_PACK_MAX_T 256
 #endif
+template <class P> constexpr bool f1_opaque() {
+    if constexpr (P::is_static) return P::T >= 512; else return false;
+}
 template <class P> constexpr bool f1_pack() {
     if constexpr (P::is_static) return P::T <= SM_ROW_PACK_MAX_T; else return true;
 }
@@ -424,7 +427,9 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         },
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;          // final gather: pairs (k, C-k)
-            const int g = tid / T, t = tid % T;
+            int tid_ = tid;
+            if constexpr (f1_opaque<P>()) SM_OPAQUE(tid_);         // 128-VGPR plans: addresses recomputed here, not carried from the top
+            const int g = tid_ / T, t = tid_ % T;
             const float* l = lds + g * LF;
             float* o = comp_of<comp>(s);
 #pragma unroll
@@ -443,7 +448,9 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         });
 
     ex.each(st, [&](int tid, FftState& s) {
-        const int g = tid / T, t = tid % T;
+        int tid_ = tid;
+        if constexpr (f1_opaque<P>()) SM_OPAQUE(tid_);
+        const int g = tid_ / T, t = tid_ % T;
         const int row = bid * p.nb + g;
         if (row >= p.R) return;
         cf4* dst = p.t1 + (size_t)(row / p.ilv) * p.pitch4 * p.ilv + (row % p.ilv);
