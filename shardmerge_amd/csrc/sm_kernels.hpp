@@ -942,6 +942,11 @@ template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
 }
 
+#ifndef SM_F2S_ILV
+#define SM_F2S_ILV 1        // 2 = row PAIRS interleaved in the single-signal T1 (64-byte pieces for the column pass): measured on
+                            // MI355X it takes 4-12 % off f2s and puts 8-12 % on the row pass (half-line stores) - net loss
+#endif
+constexpr int F2S_ILV = SM_F2S_ILV;
 template <class P, int G, bool FOLD = false, class Ex>
 SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     if constexpr (FOLD && !fold_col_plan<P>()) { return; } else {
@@ -964,12 +969,13 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         const int k2 = kbase + b;
 #pragma unroll
         for (int q = 0; q < EMAX / 2; ++q) {
-            const int m = lane + q * T;
+            const int m = F2S_ILV * (lane + (q / F2S_ILV) * T) + q % F2S_ILV;      // row pair (rows 2m, 2m+1)
             cf4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (FOLD) {
-                if (m < half && k2 < p.Cb) v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + (size_t)m * p.slab + (k2 % p.slab)];
+                if (m < half && k2 < p.Cb)
+                    v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)(m / F2S_ILV) * p.slab + (k2 % p.slab)) * F2S_ILV + m % F2S_ILV];
             } else {
-                if (m < half && k2 < p.Cb) v = p.t1[(size_t)m * p.pitch4 + k2];
+                if (m < half && k2 < p.Cb) v = p.t1[((size_t)(m / F2S_ILV) * p.pitch4 + k2) * F2S_ILV + m % F2S_ILV];
             }
             s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
         }
@@ -984,7 +990,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
             float* la = lds + b * LF;
 #pragma unroll
             for (int q = 0; q < EMAX / 2; ++q) {
-                const int m = lane + q * T;
+                const int m = F2S_ILV * (lane + (q / F2S_ILV) * T) + q % F2S_ILV;
                 if (m < half) { la[lpad(2 * m)] = x[2 * q]; la[lpad(2 * m + 1)] = x[2 * q + 1]; }
             }
         },

@@ -485,7 +485,7 @@ class Pipeline {
         SigDesc a = sig, b = sig;
         b.x = (const char*)sig.x + (size_t)g.C * dt_size(sig.dtype);
         if (sig.base) b.base = (const char*)sig.base + (size_t)g.C * dt_size(sig.dtype);
-        p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = 1;
+        p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = F2S_ILV;
         p.nb = std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)2 * g.C;
         p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
@@ -496,13 +496,14 @@ class Pipeline {
             if (!p.vec) return fail(SMHIP_ERR_ARG, "internal: folded row pass on unaligned input");
             FftPlanDev colp;
             if ((rc = get_plan(g.R, colp))) return rc;
-            p.R2 = g.R / 8; p.rowpair = 1; p.twR = colp.tw; p.ilv = 1; p.nb = 4;      // units = row pairs
-            const int gridq = (int)round_up((size_t)p.R2, 8);
+            p.R2 = g.R / 8; p.rowpair = 1; p.twR = colp.tw; p.ilv = F2S_ILV; p.nb = 4;      // units = row pairs
+            const int gridq = (int)round_up((size_t)p.R2, 8 * p.ilv);
             launch_fft<KF1Q>(p.plan, gridq, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
             if (grid_out) *grid_out = gridq;
             return SMHIP_OK;
         }
-        const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8);
+        const int xgs = p.ilv > p.nb ? p.ilv / p.nb : 1;
+        const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8 * xgs);
         if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
         launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
