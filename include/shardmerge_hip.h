@@ -116,6 +116,10 @@ typedef struct {
                                                kernel returns it (8 fp32 lanes accumulated serially: biased by
                                                -5e-3 at 67 M elements), which the reference's device="cpu" output
                                                depends on at the 1e-2 level; ~20 ms per 8192 x 8192 norm */
+    int batch;                              /* 0 / 1: one [rows x cols] tensor.  > 1: a rank > 2 tensor, `batch` contiguous
+                                               slices [rows x cols]: each slice is transformed on its own (the reference's
+                                               fftn(dim=(-2,-1)), functions.py:58) while every norm, order statistic and
+                                               slerp sum runs over the whole tensor, as the reference's flat ops do */
 } smhip_layer_desc;
 
 typedef struct {

@@ -46,6 +46,7 @@ class LayerDesc(C.Structure):
         ("t_sum", C.c_double),
         ("b", C.c_double),
         ("norm_mode", C.c_int),
+        ("batch", C.c_int),
     ]
 
 

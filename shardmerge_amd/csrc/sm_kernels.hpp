@@ -165,17 +165,22 @@ SM_HD int xcd_remap(int bid, int G) {
 // column C/2, else 2 - two range tests instead of a division per element
 struct WeightRanges {
     size_t hi0, loN, hiN;
+    size_t period;      // > 0: the planes hold a BATCH of half spectra one after the other ((C/2+1)*R elements each)
     int full;
 };
-SM_HD WeightRanges weight_ranges(int R, int C) {
+// Cb_total: bin columns in the planes; more than C/2 + 1 of them means a batch (rank > 2 tensors:
+// the reference transforms the last two dims and takes every statistic over the whole tensor)
+SM_HD WeightRanges weight_ranges(int R, int C, int Cb_total = 0) {
     WeightRanges w;
     w.full = C < 0;
     w.hi0 = (size_t)R;
     if (C >= 0 && (C % 2) == 0 && C > 0) { w.loN = (size_t)(C / 2) * R; w.hiN = w.loN + R; }
     else { w.loN = w.hiN = 0; }
+    w.period = (C >= 0 && Cb_total > C / 2 + 1) ? (size_t)(C / 2 + 1) * R : 0;
     return w;
 }
 SM_HD uint32_t weight_at(const WeightRanges& w, size_t i) {
+    if (w.period) i %= w.period;
     return (w.full || i < w.hi0 || (i >= w.loN && i < w.hiN)) ? 1u : 2u;
 }
 
@@ -1541,7 +1546,7 @@ SM_HD void k_hist(Ex& ex, const HistParams& p) {
     const size_t nquad = (total + 3) / 4;
     if (p.only_if && !*p.only_if) return;
     const uint32_t prefix = p.sel->prefix;
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < nbins; b += nt) lh[b] = 0; });
     ex.sync();
     ex.each(st, [&](int tid, EmptyState&) {
@@ -1641,7 +1646,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
         });
     }
     ex.sync();
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0;
         if (tid < 8) lctl[tid] = 0;
@@ -2017,7 +2022,7 @@ SM_HD void k_reduce(Ex& ex, const ReduceParams& p) {
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
     const float thr = p.thr ? *p.thr : 0.f;
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     const bool skip = p.only_if && !*p.only_if;
     ex.each(st, [&](int tid, EmptyState& s) {
         double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
@@ -2180,7 +2185,7 @@ SM_HD void k_blend(Ex& ex, const BlendParams& p) {
     BlendConsts c;
     memset(&c, 0, sizeof(c));
     if (p.mode == BLEND_SLERP) c = *p.consts;
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     if (p.hist) {
         ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
         ex.sync();
@@ -2277,7 +2282,7 @@ SM_HD void k_spec_norm(Ex& ex, const SpecNormParams& p) {
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
     const float thr = p.thr ? *p.thr : 0.f;
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     ex.each(st, [&](int tid, EmptyState& s) {
         double sr = 0, si = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
@@ -2350,7 +2355,7 @@ SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
     const int nt = ex.nthreads();
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
-    const WeightRanges wr = weight_ranges(p.R, p.C);
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     if (p.hist) {
         ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
         ex.sync();

@@ -291,6 +291,10 @@ class Pipeline {
         bool full;                // planes hold the full spectrum (weights 1)
         int Cw;                   // C passed to bin_weight (-1 in full mode)
         int fold;                 // 4: radix-4 column step folded into the row pass (k_f1q), else 1
+        int batch;                // > 1: rank > 2 tensor = `batch` slices [R x C]; transforms per slice, statistics
+                                  // over everything (the reference: fftn(dim=(-2,-1)), functions.py:58); Cb then
+                                  // counts the bin columns of ALL slices (the planes hold them one after the other)
+        size_t t1_slice;          // float4 of T1 per slice
     };
     // shapes whose column pass runs folded: a long column (its own plan needs >= 512 threads per
     // transform) over rows short enough for four of them to share a work-group
@@ -305,12 +309,14 @@ class Pipeline {
         return 4 * T <= 1024 && (C / T) % 2 == 0 && C % 8 == 0;
     }
     bool fold_enabled = true;
-    Geo geo(int R, int C, bool full = false, bool allow_fold = false) const {
+    Geo geo(int R, int C, bool full = false, bool allow_fold = false, int batch = 1) const {
         Geo g;
         g.R = R; g.C = C; g.full = full;
-        g.fold = (allow_fold && fold_enabled && !full && fold_shape(R, C)) ? 4 : 1;
-        g.Cb = full ? C : C / 2 + 1;
+        g.batch = batch < 1 ? 1 : batch;
+        g.fold = (allow_fold && fold_enabled && !full && g.batch == 1 && fold_shape(R, C)) ? 4 : 1;
+        g.Cb = full ? C : (C / 2 + 1) * g.batch;
         g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
+        g.t1_slice = round_up((size_t)R, 8) * (size_t)g.pitch4;
         g.pitchG = g.pitch4;           // G: row pairs x bins, float4 (two rows' float2) per entry
         g.ilv = t1_interleave(R);
         g.plane_floats = round_up((size_t)g.Cb * R, 64);
@@ -329,10 +335,10 @@ class Pipeline {
 #endif
     static int t1_interleave(int R) { return t1_interleave_rows(R); }
     static constexpr int MAXGRID_PART = 1 << 20;
-    int reserve(int R, int C, bool full = false) {
-        const Geo g = geo(R, C, full);
+    int reserve(int R, int C, bool full = false, int batch = 1) {
+        const Geo g = geo(R, C, full, false, batch);
         int rc;
-        if ((rc = ensure(t1_, round_up((size_t)R, 4) * g.pitch4 * sizeof(cf4)))) return rc;
+        if ((rc = ensure(t1_, g.t1_slice * g.batch * sizeof(cf4)))) return rc;
         for (int i = 0; i < 4; ++i)
             if ((rc = ensure(pool_[pidx_[i]], g.plane_floats * sizeof(float)))) return rc;
         {   // candidate lists of the selection passes: ~1 % of the data is expected
@@ -464,14 +470,25 @@ class Pipeline {
         }
         const int xg = p.ilv > p.nb ? p.ilv / p.nb : 1;
         const int grid = (int)round_up((size_t)(g.R + p.nb - 1) / p.nb, 8 * xg);
-        if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        if ((size_t)grid * 2 * g.batch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
-        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
-        grid_out = grid;
+        for (int bi = 0; bi < g.batch; ++bi) {          // one launch per slice of a rank > 2 tensor
+            p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
+            p.t1 = (cf4*)t1_.p + (size_t)bi * g.t1_slice;
+            p.partials = d_part() + (size_t)bi * 2 * grid;
+            launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+        }
+        grid_out = grid * g.batch;
         return SMHIP_OK;
     }
     // ---- one signal (rounds >= 2: the pair's other input stayed spectral) ---------------------
     static size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+    static SigDesc sig_at(const SigDesc& s, size_t elems) {        // the signal `elems` elements further on (next slice of a batch)
+        SigDesc r = s;
+        if (r.x) r.x = (const char*)r.x + elems * dt_size(s.dtype);
+        if (r.base) r.base = (const char*)r.base + elems * dt_size(s.dtype);
+        return r;
+    }
     // rows (2m, 2m+1) of ONE signal as the two operands of the two-for-one row transform:
     // T1[m][k] = (spectrum of row 2m, spectrum of row 2m+1).  R must be even.
     // float4 per k1 slab of the folded T1 (R/4 rows of one real pitch)
@@ -504,10 +521,17 @@ class Pipeline {
         }
         const int xgs = p.ilv > p.nb ? p.ilv / p.nb : 1;
         const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8 * xgs);
-        if ((size_t)grid * 2 > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        if ((size_t)grid * 2 * g.batch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
-        launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
-        if (grid_out) *grid_out = grid;
+        cf4* const t1base = p.t1;
+        double* const pbase = p.partials;
+        for (int bi = 0; bi < g.batch; ++bi) {
+            p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
+            p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
+            p.partials = pbase + (size_t)bi * 2 * grid;
+            launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+        }
+        if (grid_out) *grid_out = grid * g.batch;
         return SMHIP_OK;
     }
     int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr) {
@@ -526,8 +550,14 @@ class Pipeline {
         const int xg = G >= 8 ? 1 : 8 / G;
         const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
-        if (g.fold == 4) launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p);
-        else launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
+        if (g.fold == 4) { launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p); return SMHIP_OK; }
+        const cf4* const t1base = p.t1;
+        const size_t pslice = (size_t)(g.C / 2 + 1) * g.R;              // plane floats per slice
+        for (int bi = 0; bi < g.batch; ++bi) {
+            p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
+            p.re = plane(g, role_a ? P_REA : P_REB) + bi * pslice; p.im = plane(g, P_IMA) + bi * pslice;
+            launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
+        }
         return SMHIP_OK;
     }
     // sum over the full spectrum of |R_culled|^2 of the planes (re, im) -> (sum_re, sum_im), one sync
@@ -609,7 +639,12 @@ class Pipeline {
         const int ngroups = p.nsig == 2 ? 2 * bins : 1;
         const int grid = p.nsig == 2 ? (int)round_up((size_t)(p.Cb + bins - 1) / bins, 64) : (int)round_up((size_t)p.Cb * 2, 128);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)ngroups * p.plan.lds_floats + HIST1_BINS) * 4;
-        launch_fft<KF2>(p.plan, grid, ngroups * p.plan.T, lds, p);
+        const size_t pslice = (size_t)(g.C / 2 + 1) * g.R;              // plane floats per slice
+        for (int bi = 0; bi < g.batch; ++bi) {
+            p.t1 = (const cf4*)t1_.p + (size_t)bi * g.t1_slice;
+            p.reA = plane(g, P_REA) + bi * pslice; p.imA = plane(g, P_IMA) + bi * pslice; p.reB = plane(g, P_REB) + bi * pslice;
+            launch_fft<KF2>(p.plan, grid, ngroups * p.plan.T, lds, p);
+        }
         return SMHIP_OK;
     }
 
@@ -719,21 +754,11 @@ class Pipeline {
         int rc = get_plan(g.R, a.plan);
         if (rc) return rc;
         const int Cb = g.C / 2 + 1;
-        a.reR = reR; a.imA = imA; a.cull_thr = cull_thr; a.cull_val = cull_val; a.R = g.R; a.Cb = Cb;
-        if (g.R == 1) {
-            a.s = 1; a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
-            be.template launch<KI1R1>(std::max(1, std::min(64, (Cb + 255) / 256)), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
-        } else {
-        a.s = i1_bins_host(a.plan);
+        a.cull_thr = cull_thr; a.cull_val = cull_val; a.R = g.R; a.Cb = Cb;
         a.G = (cf2*)t1_.p; a.pitchG = g.pitchG;
+        a.s = g.R == 1 ? 1 : i1_bins_host(a.plan);
         const size_t lds1 = (LDS_SCRATCH_FLOATS + (size_t)a.s * a.plan.lds_floats) * 4;
         const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
-        if (g.fold == 4) {
-            if (a.s >= 2) launch_fft<KI1x2Q>(a.plan, grid1, a.s * a.plan.T, lds1, a);
-            else launch_fft<KI1x1Q>(a.plan, grid1, a.plan.T, lds1, a);
-        } else if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
-        else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
-        }
 
         I2Params b;
         if ((rc = get_plan(g.C, b.plan))) return rc;
@@ -742,14 +767,28 @@ class Pipeline {
         b.vec = (g.C % 8 == 0) && aligned16(o.out) && aligned16(o.base);
         b.inv_n = (float)(1.0 / ((double)g.R * (double)g.C));
         b.ifft_policy = o.ifft_policy;
-        b.post = o.post; b.base = o.base; b.base_dtype = o.base_dtype; b.out = o.out; b.out_mode = o.out_mode;
+        b.post = o.post; b.base_dtype = o.base_dtype; b.out_mode = o.out_mode;
         b.flags = d_flags();
         const int pairs = (g.R + 1) / 2;
         const int grid2 = (pairs + b.nb - 1) / b.nb;
-        b.norm_partials = (norm_grid && (size_t)grid2 * 2 <= PART_DOUBLES) ? d_part() : nullptr;
-        if (norm_grid) *norm_grid = b.norm_partials ? grid2 : -1;
+        const bool want_norm = norm_grid && (size_t)grid2 * 2 * g.batch <= PART_DOUBLES;
+        if (norm_grid) *norm_grid = want_norm ? grid2 * g.batch : -1;
         const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
-        launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
+        const size_t pslice = (size_t)Cb * g.R, eslice = (size_t)g.R * g.C;
+        for (int bi = 0; bi < g.batch; ++bi) {            // per slice: columns, then rows (T1 is reused)
+            a.reR = reR + bi * pslice; a.imA = imA + bi * pslice;
+            if (g.R == 1) {
+                be.template launch<KI1R1>(std::max(1, std::min(64, (Cb + 255) / 256)), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+            } else if (g.fold == 4) {
+                if (a.s >= 2) launch_fft<KI1x2Q>(a.plan, grid1, a.s * a.plan.T, lds1, a);
+                else launch_fft<KI1x1Q>(a.plan, grid1, a.plan.T, lds1, a);
+            } else if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
+            else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
+            b.base = o.base ? (const char*)o.base + bi * eslice * dt_size(o.base_dtype) : nullptr;
+            b.out = (char*)o.out + bi * eslice * (o.out_mode == OUT_BF16 ? 2 : 4);
+            b.norm_partials = want_norm ? d_part() + (size_t)bi * 2 * grid2 : nullptr;
+            launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
+        }
         return SMHIP_OK;
     }
 
@@ -805,7 +844,7 @@ class Pipeline {
     // the (scaled) half spectra.  Leaves Re R in P_RER and the cull threshold in d_thr(1).
     void spectral_blend(const Geo& g, int mode, double t, double t_sum, double cutoff_pct, double cull_pct,
                         int agreement, bool level1_hist_done, bool& have_cull) {
-        const unsigned long long nfull = g.full ? (unsigned long long)g.R * g.C : (unsigned long long)g.R * g.C;
+        const unsigned long long nfull = (unsigned long long)g.R * g.C * (unsigned long long)g.batch;
         have_cull = false;
         if (mode == BLEND_SLERP) {
             const bool have_cut = cutoff_pct > 0;
@@ -1085,7 +1124,7 @@ class Pipeline {
     int rows_first(const Geo& g, std::vector<Slot>& stack) {
         const int k = (int)stack.size();
         if ((int)rowspec_.size() < k) rowspec_.resize(k);
-        const size_t bytes = round_up((size_t)g.R, 8) / 2 * (size_t)g.pitch4 * sizeof(cf4) + 4096;
+        const size_t bytes = (g.t1_slice / 2) * g.batch * sizeof(cf4) + 4096;
         int rc;
         std::vector<int> grids(k);
         size_t poff = 0;
@@ -1112,10 +1151,12 @@ class Pipeline {
         if (d.k < 1 || d.k > SMHIP_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
         const int R = d.rows, C = d.cols;
         if (R < 1 || C < 1) return fail(SMHIP_ERR_ARG, "bad shape");
-        const size_t n = (size_t)R * C;
+        const int batch = d.batch > 1 ? d.batch : 1;          // rank > 2: `batch` slices [R x C], statistics over all of them
+        if (batch > 1 && R < 2) return fail(SMHIP_ERR_ARG, "a batch of 1-D slices: pass it as a 2-D tensor");
+        const size_t n = (size_t)R * C * batch;
         bool all_aligned = aligned16(d.base_out) && aligned16(out_bf16) && aligned16(delta_out);
         for (int i = 0; i < d.k; ++i) all_aligned = all_aligned && aligned16(d.finetune[i]) && aligned16(d.base[i]);
-        const Geo g = geo(R, C, false, all_aligned);
+        const Geo g = geo(R, C, false, all_aligned, batch);
         int rc;
         if (!small_.p && (rc = reserve(1, 1))) return rc;
         clear_flags();
@@ -1145,7 +1186,7 @@ class Pipeline {
             rp.delta_norm[0] = na; rp.target_norm = (double)(float)na + d.target_norm_offset; rp.merged_delta_norm = na;
             return check_flags(false, true, &rp.nan_ifft, &rp.nan_final);
         }
-        if ((rc = reserve(R, C))) return rc;
+        if ((rc = reserve(R, C, false, batch))) return rc;
 
         // norms of every delta.  K == 2: fused into the (speculative) F1 of the only pair.
         std::vector<float> norms32(d.k);
@@ -1157,7 +1198,7 @@ class Pipeline {
             read_norms(f1_grid, na, nb);
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
-        } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(R / 2 + 8) <= PART_DOUBLES &&
+        } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(R / 2 + 8) * batch <= PART_DOUBLES &&
                    rows_first(g, stack) == SMHIP_OK) {
             // K >= 3: every delta's ROWS are transformed up front, one signal at a time (row pairs);
             // the norms come with it (no separate pass over the inputs), and whichever deltas the
@@ -1365,7 +1406,7 @@ class Pipeline {
                             double sre, sim;
                             run_spec_norm(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, sre, sim);
                             read_blend_info(&info, d.cutoff_pct > 0, have_cull, true, /*published=*/true);
-                            const double ssum = (sre + sim) / (double)n;
+                            const double ssum = (sre + sim) / ((double)R * (double)C);     // Parseval per [R x C] transform (slices add up)
                             out_spectral = true;
                             spec_slot = Slot();
                             spec_slot.spectral = true;

@@ -75,8 +75,20 @@ def _shape2d(t: torch.Tensor) -> Tuple[int, int]:
         return 1, t.shape[0]
     if t.ndim == 2:
         return t.shape[0], t.shape[1]
-    # the reference transforms the last two dims of an N-D tensor; model weights are 1-D / 2-D
-    raise NotImplementedError(f"tensor of rank {t.ndim} is not supported by the HIP path")
+    # (merge_layer and the plain transforms take rank > 2 through _shape3d)
+    raise NotImplementedError(f"tensor of rank {t.ndim} is not supported by this entry point of the HIP path")
+
+
+def _shape3d(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(batch, rows, cols): the reference transforms the LAST TWO dims of an N-D tensor
+    (functions.py:55-58); every leading dim is batch."""
+    if t.ndim <= 2:
+        r, c = _shape2d(t)
+        return 1, r, c
+    b = 1
+    for d in t.shape[:-2]:
+        b *= int(d)
+    return b, int(t.shape[-2]), int(t.shape[-1])
 
 
 class Engine:
@@ -116,17 +128,21 @@ class Engine:
     # -- A4 / A8 -----------------------------------------------------------------
     def fft_transform(self, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x, torch.float32)
-        r, c = _shape2d(x)
+        b, r, c = _shape3d(x)
         out = torch.empty(x.shape + (2,), dtype=torch.float32, device=self.device)
-        self._call(self.lib.dll.smhip_fft_transform(self.ctx.h, x.data_ptr(), r, c, out.data_ptr(), self._stream()))
+        xs, os_ = x.reshape(b, -1), out.reshape(b, -1)
+        for i in range(b):                        # slices of a rank > 2 tensor are independent transforms
+            self._call(self.lib.dll.smhip_fft_transform(self.ctx.h, xs[i].data_ptr(), r, c, os_[i].data_ptr(), self._stream()))
         return torch.view_as_complex(out)
 
     def ifft_transform(self, spec: torch.Tensor) -> torch.Tensor:
         spec = self._dev(spec, torch.complex64)
-        r, c = _shape2d(spec)
+        b, r, c = _shape3d(spec)
         sr = torch.view_as_real(spec)
         out = torch.empty(spec.shape, dtype=torch.float32, device=self.device)
-        self._call(self.lib.dll.smhip_ifft_transform(self.ctx.h, sr.data_ptr(), r, c, out.data_ptr(), self._stream()))
+        ss, os_ = sr.reshape(b, -1), out.reshape(b, -1)
+        for i in range(b):
+            self._call(self.lib.dll.smhip_ifft_transform(self.ctx.h, ss[i].data_ptr(), r, c, os_[i].data_ptr(), self._stream()))
         return out
 
     # -- A5 - A7 -------------------------------------------------------------------
@@ -234,7 +250,7 @@ class Engine:
         if bo is None or bo.dtype != bo_dtype:
             bo = self._dev(base_out, bo_dtype)
         keep.append(bo)
-        r, c = _shape2d(bo)
+        nb, r, c = _shape3d(bo)
         desc.in_dtype = _DTYPE_CODE[in_dtype]
         desc.base_out = bo.data_ptr()
         desc.base_out_dtype = _DTYPE_CODE[bo_dtype]
@@ -247,6 +263,7 @@ class Engine:
         if norm_mode not in ("exact", "reference_cpu"):
             raise ValueError(f"norm_mode {norm_mode!r}: 'exact' or 'reference_cpu'")
         desc.norm_mode = 1 if norm_mode == "reference_cpu" else 0
+        desc.batch = nb
         out = torch.empty(bo.shape, dtype=torch.bfloat16, device=self.device)
         delta = torch.empty(bo.shape, dtype=torch.float32, device=self.device) if want_delta else None
         rep = LayerReport()

@@ -192,9 +192,12 @@ def check_layer_steps(rep, tr, numel, reported_fields=True, biased_slerp_norms=F
             assert info.cull_pct == bt.cull_pct, f"step {i}: cull fraction {info.cull_pct} vs {bt.cull_pct}"
         if n_inter[i] == 0:
             first_cut = bt.cutoff_threshold if first_cut is None else first_cut
-            assert abs(info.cutoff_threshold - bt.cutoff_threshold) <= 1e-5 * bt.cutoff_threshold + 1e-30, f"step {i} cutoff"
+            # neighbouring order statistics are ~1/(0.2 n) apart (relative): a rank shifted by one
+            # through FFT rounding shows at small sizes
+            gran = 8.0 / max(numel, 1)
+            assert abs(info.cutoff_threshold - bt.cutoff_threshold) <= max(1e-5, gran) * bt.cutoff_threshold + 1e-30, f"step {i} cutoff"
             loose = 100.0 if biased_slerp_norms else 1.0
-            assert abs(info.cull_threshold - bt.cull_threshold) <= loose * 5e-5 * bt.cull_threshold + 1e-30, f"step {i} cull"
+            assert abs(info.cull_threshold - bt.cull_threshold) <= loose * max(5e-5, gran) * bt.cull_threshold + 1e-30, f"step {i} cull"
             assert abs(info.n_slerp - bt.n_slerp) <= 4 + 1e-4 * bt.n_slerp, f"step {i} n_slerp"
             assert abs(info.dot - bt.dot) <= loose * 1e-4, f"step {i} dot"
         else:

@@ -414,3 +414,37 @@ def test_norm_mode_reference_cpu_reproduces_torch_norm(engine):
             assert pc.spectral_residual(delta.cpu(), tr.merged_delta)[1] < 2e-5
     with pytest.raises(ValueError):
         engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, norm_mode="fast")
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_rank3_tensor_is_a_batch_of_transforms_with_global_statistics(engine, k):
+    """The reference transforms the LAST TWO dims of an N-D tensor (fftn(dim=(-2,-1)),
+    functions.py:55-58) while its norms, quantiles and slerp sums are flat over the whole tensor
+    (fused MoE expert weights [E, R, C]).  merge_layer takes such a tensor as `batch` slices."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(40 + k)
+    shape = (3, 128, 256) if k == 2 else (2, 2, 128, 128)
+    base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16) for s_ in (0.002, 0.003, 0.0025)[:k]]
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    out, delta = out.cpu(), delta.cpu()
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16
+    pc.check_layer_steps(rep, tr, out.numel())
+    r, c = shape[-2], shape[-1]
+    if k == 2:
+        d_total, d_resid = pc.spectral_residual(delta.reshape(-1, c), tr.merged_delta.reshape(-1, c))
+        assert d_resid < 2e-5 and so.rel_err(out.float(), ref.float()) < 1e-3
+        # NOT the same as merging the slices one by one (per-slice thresholds and norms)
+        one = engine.merge_layer([f[0] for f in fts], [base[0]] * k, so.ALPHAS[:k], base[0], want_delta=True)[2].cpu()
+        assert so.rel_err(one, tr.merged_delta[0]) > 1e-3
+    else:
+        assert so.rel_err(out.float(), ref.float()) < 5e-3
+        assert so.rel_err(delta, tr.merged_delta) < 3e-2          # K = 3: the reference's own chaos floor (DESIGN 6.2)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    f = engine.fft_transform(x).cpu()
+    assert so.rel_err(torch.view_as_real(f), torch.view_as_real(so.fft_transform(x))) < 3e-6
+    assert so.rel_err(engine.ifft_transform(f).cpu(), x) < 3e-6
+    with pytest.raises(NotImplementedError):
+        engine.merge_tensors_fft2_slerp(x, x, 0.5)               # the function-level pair API is 1-D / 2-D

@@ -542,3 +542,8 @@ def test_partitioned_merge_through_rccl_world_size_1(tmp_path, golden):
                     assert so.rel_err(got.float(), ref.float()) < 2e-3
                 else:
                     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_rank3_tensor_on_device(engine, k):
+    emul_tier.test_rank3_tensor_is_a_batch_of_transforms_with_global_statistics(engine, k)
