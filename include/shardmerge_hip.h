@@ -147,6 +147,15 @@ int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf
 int smhip_addition_merge(smhip_ctx* ctx, int k, const void* const* finetunes, const void* base, int dtype, size_t n,
                          int sign_agreement, void* out, void* stream);
 
+/* ---- correlate_pairs (reference shard/tensor/functions.py:304-314, the legacy fourier.py operator's
+ *      pairing matrix): matrix[i][j] = mean over the trailing positions of
+ *      cosine_similarity(t_i, t_j, dim=0).nan_to_num(0); zero diagonal.  tensors: k (2..8) device
+ *      tensors of `dtype`, viewed as [rows = shape[0]] x [cols = the rest] (1-D: cols = 1).
+ *      matrix_out: HOST float[k*k].  (The legacy operator's task_add_models post-pass,
+ *      fourier.py:191-196, is smhip_task_arithmetic_fft2(result, delta, t = 1, agreement = 0).) ---- */
+int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int dtype, size_t rows, size_t cols,
+                          float* matrix_out, void* stream);
+
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
  *      lists (0 = default) so that the overflow fallback can be exercised;
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass and

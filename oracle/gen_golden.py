@@ -239,7 +239,23 @@ def gen_addition(manifest):
     save_file(store, str(OUT / "g9_addition.safetensors"))
 
 
+def gen_corr(manifest):
+    """G10: the reference's correlate_pairs (functions.py:304-314)."""
+    manifest["corr"] = {}
+    for case in gi.CORR_CASES:
+        t = gi.corr_input(case)
+        m = ref_fn.correlate_pairs(t.clone(), "cpu", "cpu")
+        manifest["corr"][case["id"]] = [[float(v) for v in row] for row in m]
+        manifest["inputs"][case["id"]] = gi.checksum(t)
+
+
 def main():
+    if "--only-corr" in sys.argv:
+        manifest = json.load(open(OUT / "manifest.json"))
+        gen_corr(manifest)
+        with open(OUT / "manifest.json", "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if "--only-addition" in sys.argv:            # add G9 without touching the other fixtures
         manifest = json.load(open(OUT / "manifest.json"))
         gen_addition(manifest)
@@ -255,6 +271,7 @@ def main():
     gen_layers(manifest)
     gen_cli(manifest)
     gen_addition(manifest)
+    gen_corr(manifest)
     with open(OUT / "manifest.json", "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     total = sum(p.stat().st_size for p in OUT.glob("*.safetensors"))

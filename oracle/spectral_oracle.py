@@ -327,6 +327,18 @@ def correlated_pairs(corr: torch.Tensor, way: str = "least") -> Iterator[Tuple[i
         yield (i, -1, corr[i, i].item())
 
 
+def correlate_pairs(tensors: torch.Tensor) -> torch.Tensor:
+    """reference shard/tensor/functions.py:304-314 (devices fixed to cpu): mean over the trailing
+    positions of the cosine similarity along dim 0, NaN -> 0; symmetric, zero diagonal."""
+    k = tensors.shape[0]
+    out = torch.zeros(k, k)
+    for i in range(k):
+        for j in range(i + 1, k):
+            c = torch.nn.functional.cosine_similarity(tensors[i], tensors[j], dim=0)
+            out[i, j] = out[j, i] = c.nan_to_num(0).mean().item()
+    return out
+
+
 def name_hash(name: str) -> str:
     """reference shard/merge/fast_fourier.py:36-41."""
     short = "_".join(part[:4] for part in name.split("_"))

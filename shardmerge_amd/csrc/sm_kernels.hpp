@@ -2111,6 +2111,7 @@ struct Mailbox {
     float thr[4];               // d_thr(0..3)
     BlendConsts consts;
     float snorm[16];            // k_serial_norm results (norm_mode = reference_cpu)
+    float corr[64];             // k_corr_finish: the K x K matrix of correlate_pairs
 };
 struct PublishParams {
     const uint32_t* flags;      // device flags + counters (12 words)
@@ -2834,6 +2835,102 @@ SM_HD void k_addition(Ex& ex, const AdditionParams& p) {
                 }
             }
         }
+    });
+}
+
+// =====================================================================
+// correlate_pairs (reference shard/tensor/functions.py:304-314; used by the legacy fourier.py
+// operator's pairing): matrix[i][j] = mean over the trailing positions of
+// cosine_similarity(t_i, t_j, dim=0).nan_to_num(0).  The tensors are viewed as [rows = shape[0]]
+// x [cols = the rest]; one thread owns a column and walks a slice of the rows (coalesced across
+// the lanes); partial sums of the K(K+1)/2 products go to a workspace, a second kernel finishes.
+// =====================================================================
+constexpr int CORR_MAX_K = 8;
+constexpr int CORR_MAX_P = CORR_MAX_K * (CORR_MAX_K + 1) / 2;
+struct CorrPartialParams {
+    int k;
+    const void* t[CORR_MAX_K];
+    int dtype;
+    size_t rows, cols;
+    int splits;                 // row slices (grid y)
+    double* part;               // [splits][P][cols]
+};
+SM_HD int corr_pair_index(int i, int j, int k) { return i * k - i * (i - 1) / 2 + (j - i); }     // i <= j
+template <class Ex>
+SM_HD void k_corr_partial(Ex& ex, const CorrPartialParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t cblocks = (p.cols + nt - 1) / nt;
+    const size_t cb = (size_t)ex.bid() % cblocks, sp = (size_t)ex.bid() / cblocks;
+    const int P = p.k * (p.k + 1) / 2;
+    const size_t r0 = p.rows * sp / p.splits, r1 = p.rows * (sp + 1) / p.splits;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t c = cb * nt + tid;
+        if (c >= p.cols) return;
+        double acc[CORR_MAX_P];
+#pragma unroll
+        for (int q = 0; q < CORR_MAX_P; ++q) acc[q] = 0.0;
+        for (size_t r = r0; r < r1; ++r) {
+            float v[CORR_MAX_K];
+#pragma unroll
+            for (int i = 0; i < CORR_MAX_K; ++i) v[i] = i < p.k ? load_elem(p.t[i], p.dtype, r * p.cols + c) : 0.f;
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < CORR_MAX_K; ++i) {
+#pragma unroll
+                for (int j = i; j < CORR_MAX_K; ++j) {
+                    if (i < p.k && j < p.k) acc[q] += (double)v[i] * (double)v[j];
+                    if (j < p.k) ++q;            // q runs over the pairs of the first k tensors only
+                }
+            }
+        }
+        int q = 0;
+        for (int i = 0; i < p.k; ++i)
+            for (int j = i; j < p.k; ++j, ++q) p.part[((size_t)sp * P + q) * p.cols + c] = acc[q];
+    });
+}
+struct CorrFinishParams {
+    int k;
+    size_t cols;
+    int splits;
+    const double* part;
+    float eps;                  // torch.nn.functional.cosine_similarity: 1e-8
+    float* out;                 // [k][k], host-mapped
+};
+template <class Ex>
+SM_HD void k_corr_finish(Ex& ex, const CorrFinishParams& p) {
+    // one work-group per pair (i < j)
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const int P = p.k * (p.k + 1) / 2;
+    int pi = 0, pj = 0, cnt = 0;
+    for (int i = 0; i < p.k; ++i)
+        for (int j = i + 1; j < p.k; ++j, ++cnt)
+            if (cnt == ex.bid()) { pi = i; pj = j; }
+    const int qij = corr_pair_index(pi, pj, p.k), qii = corr_pair_index(pi, pi, p.k), qjj = corr_pair_index(pj, pj, p.k);
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double sum = 0.0;
+        for (size_t c = tid; c < p.cols; c += nt) {
+            double dij = 0, dii = 0, djj = 0;
+            for (int sp = 0; sp < p.splits; ++sp) {
+                dij += p.part[((size_t)sp * P + qij) * p.cols + c];
+                dii += p.part[((size_t)sp * P + qii) * p.cols + c];
+                djj += p.part[((size_t)sp * P + qjj) * p.cols + c];
+            }
+            const double ni = sqrt(dii), nj = sqrt(djj);
+            float cosv = (float)(dij / ((ni > p.eps ? ni : (double)p.eps) * (nj > p.eps ? nj : (double)p.eps)));
+            if (is_nan(cosv)) cosv = 0.f;                                    // nan_to_num(0)
+            else if (is_inf(cosv)) cosv = cosv > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+            sum += cosv;
+        }
+        s.red[0] = sum;
+    });
+    ex.template block_sum<1>(st, [&](const double* tot) {
+        const float m = (float)(tot[0] / (double)p.cols);
+        p.out[pi * p.k + pj] = m;
+        p.out[pj * p.k + pi] = m;
     });
 }
 

@@ -144,6 +144,8 @@ SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
 SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
 SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
 SM_KERNEL_TAG(KAddition, AdditionParams, "addition_merge", k_addition(ex, p))
+SM_KERNEL_TAG(KCorrPartial, CorrPartialParams, "correlate_pairs", k_corr_partial(ex, p))
+SM_KERNEL_TAG(KCorrFinish, CorrFinishParams, "correlate_finish", k_corr_finish(ex, p))
 SM_KERNEL_TAG(KSerialNorm, SerialNormParams, "serial_norm", k_serial_norm(ex, p))
 SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
@@ -1493,6 +1495,30 @@ class Pipeline {
         a.vec8 = (n % 8 == 0) && al;
         a.chunks = pick_chunks((n + 7) / 8, 256, 2, 8);
         be.template launch<KAddition>(stream_grid((n + 7) / 8, 256, a.chunks), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        return SMHIP_OK;
+    }
+
+    // ---- correlate_pairs (legacy operator's pairing matrix, functions.py:304-314) -------------
+    int correlate_pairs(int k, const void* const* tensors, int dtype, size_t rows, size_t cols, float* matrix_out) {
+        if (k < 2 || k > CORR_MAX_K) return fail(SMHIP_ERR_ARG, "correlate_pairs: 2 <= k <= 8");
+        int rc;
+        if (!small_.p && (rc = reserve(1, 1))) return rc;
+        const int P = k * (k + 1) / 2;
+        const size_t cblocks = (cols + 255) / 256;
+        int splits = (int)std::max<size_t>(1, std::min<size_t>(64, (size_t)1024 / cblocks));
+        splits = (int)std::min<size_t>((size_t)splits, std::max<size_t>(rows, 1));
+        if ((rc = ensure(tmpA_, (size_t)splits * P * cols * sizeof(double)))) return rc;
+        CorrPartialParams a;
+        a.k = k; a.dtype = dtype; a.rows = rows; a.cols = cols; a.splits = splits; a.part = (double*)tmpA_.p;
+        for (int i = 0; i < CORR_MAX_K; ++i) a.t[i] = tensors[i < k ? i : 0];
+        be.template launch<KCorrPartial>((int)(cblocks * splits), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        CorrFinishParams f;
+        f.k = k; f.cols = cols; f.splits = splits; f.part = (const double*)tmpA_.p; f.eps = 1e-8f;
+        f.out = (float*)mail_->corr;
+        for (int i = 0; i < k * k; ++i) mail_->corr[i] = 0.f;
+        be.template launch<KCorrFinish>(k * (k - 1) / 2, 256, LDS_SCRATCH_FLOATS * 4, f, stream);
+        be.sync(stream);
+        for (int i = 0; i < k * k; ++i) matrix_out[i] = mail_->corr[i];
         return SMHIP_OK;
     }
 

@@ -214,6 +214,22 @@ class Engine:
                                                      1 if sign_agreement else 0, out.data_ptr(), self._stream()))
         return out
 
+    def correlate_pairs(self, tensors) -> torch.Tensor:
+        """K x K matrix of mean column-wise cosine similarities (reference functions.py:304-314);
+        `tensors`: a stacked tensor [K, ...] or a sequence of K equally shaped tensors."""
+        ts = list(tensors.unbind(0)) if isinstance(tensors, torch.Tensor) else list(tensors)
+        k = len(ts)
+        if k < 2 or k > 8:
+            raise ValueError("correlate_pairs: 2..8 tensors")
+        dtype = ts[0].dtype if ts[0].dtype in _DTYPE_CODE and all(t.dtype == ts[0].dtype for t in ts) else torch.float32
+        ts = [self._dev(t, dtype) for t in ts]
+        rows = ts[0].shape[0] if ts[0].ndim >= 1 else 1
+        cols = ts[0].numel() // max(rows, 1)
+        ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+        out = (C.c_float * (k * k))()
+        self._call(self.lib.dll.smhip_correlate_pairs(self.ctx.h, k, ptrs, _DTYPE_CODE[dtype], rows, cols, out, self._stream()))
+        return torch.tensor(list(out), dtype=torch.float32).reshape(k, k)
+
     # -- A1 - A13 fused ------------------------------------------------------------------
     def merge_layer(self, finetunes: Sequence[torch.Tensor], bases: Sequence[torch.Tensor], alphas: Sequence[float],
                     base_out: torch.Tensor, target_norm_offset: float = 1e-10, cull_start_pct: float = 0.20,

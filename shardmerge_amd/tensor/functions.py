@@ -67,6 +67,12 @@ def arithmetic_fft_components(v0_fft, v1_fft, t: float, agreement: bool, device:
     return get_engine(device).arithmetic_fft_components(v0_fft, v1_fft, t, agreement=agreement, do_imag=do_imag)
 
 
+def correlate_pairs(tensors: torch.Tensor, work_device: str = "cuda", store_device: str = "cpu") -> torch.Tensor:
+    """reference functions.py:304-314: matrix[i, j] = mean of cosine_similarity(t_i, t_j, dim=0)
+    (NaN -> 0), zero diagonal; one HIP kernel pair instead of K^2/2 host round trips."""
+    return get_engine(work_device).correlate_pairs(tensors).to(store_device)
+
+
 def correlated_pairs(correlation_matrix: torch.Tensor, way: Literal["least", "most"] = "least") -> Generator[Tuple[int, int, float], None, None]:
     """Greedy pairing of a K x K matrix (reference functions.py:316-365): repeatedly take
     the first (row-major) unused upper-triangle cell whose |value| is minimal ('least') or

@@ -157,6 +157,23 @@ def addition_inputs(case):
     return base, fts
 
 
+# G10: correlate_pairs (legacy operator's pairing matrix)
+CORR_CASES = [
+    {"id": "corr_2d_k4", "shape": (4, 64, 48), "seed": 400},
+    {"id": "corr_1d_k3", "shape": (3, 500), "seed": 410},
+    {"id": "corr_3d_k5", "shape": (5, 7, 9, 11), "seed": 420},
+    {"id": "corr_zero_col_k3", "shape": (3, 32, 16), "seed": 430, "zero_col": True},
+]
+
+
+def corr_input(case):
+    t = _randn(case["shape"], case["seed"], 1.0)
+    if case.get("zero_col"):
+        t[0, :, 1] = 0            # a zero column: cosine 0/0 -> NaN -> 0 (nan_to_num)
+        t[1, :, 1] = 0
+    return t
+
+
 def layer_inputs(case):
     """-> (tensors by model uri, MergeModel kwargs list, config kwargs, layer name)"""
     shape, seed, k = case["shape"], case["seed"], case["k"]

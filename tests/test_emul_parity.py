@@ -448,3 +448,15 @@ def test_rank3_tensor_is_a_batch_of_transforms_with_global_statistics(engine, k)
     assert so.rel_err(engine.ifft_transform(f).cpu(), x) < 3e-6
     with pytest.raises(NotImplementedError):
         engine.merge_tensors_fft2_slerp(x, x, 0.5)               # the function-level pair API is 1-D / 2-D
+
+
+@pytest.mark.parametrize("case", gi.CORR_CASES, ids=lambda c: c["id"])
+def test_correlate_pairs(engine, golden, case):
+    """The legacy operator's pairing matrix (functions.py:304-314) against the reference's values."""
+    want = torch.tensor(golden.manifest["corr"][case["id"]])
+    got = engine.correlate_pairs(gi.corr_input(case))
+    assert got.shape == want.shape and torch.equal(got, got.T) and float(got.diagonal().abs().max()) == 0.0
+    assert float((got - want).abs().max()) < 2e-7
+    from shardmerge_amd.tensor import functions as fn      # and the pairing that follows it
+    pairs_ref = [(x, y) for x, y, _ in fn.correlated_pairs(want, "least")]
+    assert [(x, y) for x, y, _ in fn.correlated_pairs(got, "least")] == pairs_ref

@@ -547,3 +547,8 @@ def test_partitioned_merge_through_rccl_world_size_1(tmp_path, golden):
 @pytest.mark.parametrize("k", [2, 3])
 def test_rank3_tensor_on_device(engine, k):
     emul_tier.test_rank3_tensor_is_a_batch_of_transforms_with_global_statistics(engine, k)
+
+
+@pytest.mark.parametrize("case", gi.CORR_CASES, ids=lambda c: c["id"])
+def test_correlate_pairs_on_device(engine, golden, case):
+    emul_tier.test_correlate_pairs(engine, golden, case)
