@@ -942,6 +942,8 @@ struct F2SParams {
     unsigned long long* hist;
     int slab, Cb_real, Rfull;   // FOLD variant: as F2Params
     size_t slab_elems;
+    double* im_partials;        // role a only, or null: [grid] sum w (Im a)^2 of what this work-group stored
+                                // (the Parseval norm of the pair's result when it stays spectral)
 };
 template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
@@ -964,7 +966,10 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     constexpr int XG = G >= 8 ? 1 : 8 / G;                 // work-groups that share a 128-byte line of T1
     const int lbid = xcd_remap(ex.bid(), XG);
     const int kbase = lbid * G;
-    if (kbase >= p.Cb) return;
+    if (kbase >= p.Cb) {                      // padding work-group: its partial must still read zero
+        if (p.im_partials) ex.each(st, [&](int tid, FftState&) { if (tid == 0) p.im_partials[ex.bid()] = 0.0; });
+        return;
+    }
     const int nthreads = G * T;
     const int half = R / 2;
     uint32_t* lhist = (uint32_t*)(lds + G * LF);
@@ -1017,6 +1022,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
         const int k2 = kbase + g;
+        s.red[0] = 0.0;
         if (k2 >= p.Cb) return;
         const float sc = p.scale;
         size_t poff = (size_t)k2 * R;
@@ -1025,6 +1031,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
         float* dre = p.re + poff;
         float* dim = p.im + poff;
+        float imsq = 0.f;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);
@@ -1034,13 +1041,14 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
                 if (p.role_a) {
                     cf4 vi = {s.xi[4 * u] * sc, s.xi[4 * u + 1] * sc, s.xi[4 * u + 2] * sc, s.xi[4 * u + 3] * sc};
                     *(cf4*)(dim + k0) = vi;
+                    imsq += vi.x * vi.x + vi.y * vi.y + vi.z * vi.z + vi.w * vi.w;
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (k0 + c < R) {
                         dre[k0 + c] = s.xr[4 * u + c] * sc;
-                        if (p.role_a) dim[k0 + c] = s.xi[4 * u + c] * sc;
+                        if (p.role_a) { const float vi = s.xi[4 * u + c] * sc; dim[k0 + c] = vi; imsq += vi * vi; }
                     }
                 }
             }
@@ -1054,6 +1062,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
                 }
             }
         }
+        s.red[0] = (double)imsq * (double)w;
     });
     if (p.hist) {
         ex.sync();
@@ -1063,6 +1072,10 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
                 if (v) ex.global_atomic_add(&p.hist[h], (unsigned long long)v);
             }
         });
+    }
+    if (p.im_partials) {
+        ex.sync();
+        ex.template block_sum<1>(st, [&](const double* tot) { p.im_partials[ex.bid()] = tot[0]; });
     }
     }
 }
@@ -1618,7 +1631,10 @@ struct Select2Params {
     unsigned long long* hist;           // level-2 histogram (HIST_LO_BINS), accumulated here
     CandLists cand;
     int fuse_reduce;                    // needs Y: X = Re a, Y = Re b
-    double* partials;                   // [grid][4] when fuse_reduce
+    int sumsq;                          // Y == null: partials[4*wg] += sum w x^2 over the elements whose level-1 bin lies
+                                        // ABOVE the threshold's (they survive the cull whatever its low bits): the
+                                        // Parseval norm of a spectral intermediate, fused into the cull selection
+    double* partials;                   // [grid][4] when fuse_reduce or sumsq
     int chunks;
     int flush_always;          // test hook: flush the staged candidates after every round
 };
@@ -1677,6 +1693,8 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                         ex.lds_atomic_add(&lh[(ka >> 10) & 1023u], w);
                         const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
                         if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = ka | ((w - 1u) << 31);
+                    } else if (p.sumsq && (ka >> 20) > prefix) {
+                        q00 += (float)w * a[e] * a[e];
                     }
                     if (hasY) {
                         const uint32_t kb = f2u(b[e]) & 0x7fffffffu;
@@ -1773,12 +1791,55 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
         }
     });
-    if (p.fuse_reduce) {
+    if (p.fuse_reduce || p.sumsq) {
         ex.sync();
         ex.template block_sum<4>(st, [&](const double* tot) {
             for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
         });
     }
+}
+
+// the candidates' share of the Parseval sum once the cull threshold is known (sumsq above)
+struct SumsqCandParams {
+    CandLists cand;
+    const float* thr;
+    double* partials;          // [nblocks][4], appended after the selection pass's partials
+};
+template <class Ex>
+SM_HD void k_sumsq_cand(Ex& ex, const SumsqCandParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const uint32_t n = p.cand.counters[2] ? 0u : p.cand.counters[0];
+    const float thr = *p.thr;
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double acc = 0;
+        for (size_t q = (size_t)ex.bid() * nt + tid; q < n; q += (size_t)ex.nblocks() * nt) {
+            const uint32_t v = p.cand.keys[q];
+            const float x = u2f(v & 0x7fffffffu);
+            if (!(x < thr)) acc += (double)(1u + (v >> 31)) * (double)x * (double)x;
+        }
+        s.red[0] = acc; s.red[1] = 0; s.red[2] = 0; s.red[3] = 0;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
+    });
+}
+// S_re = sum of partials[4i], S_im = sum of im_partials[i] -> out[0], out[1]; clears the list counters
+struct SumSpecParams { const double* part4; int n4; const double* part1; int n1; double* out; uint32_t* zero_u32; int zero_u32_count; };
+template <class Ex>
+SM_HD void k_sum_spec(Ex& ex, const SumSpecParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double a0 = 0, a1 = 0;
+        for (int i = tid; i < p.n4; i += nt) a0 += p.part4[4 * (size_t)i];
+        for (int i = tid; i < p.n1; i += nt) a1 += p.part1[i];
+        if (p.zero_u32 && tid < p.zero_u32_count) p.zero_u32[tid] = 0u;
+        s.red[0] = a0; s.red[1] = a1;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) { p.out[0] = tot[0]; p.out[1] = tot[1]; });
 }
 
 // level 3 on the candidate list (or nothing when the list overflowed)
@@ -2347,6 +2408,7 @@ struct SpecRescaleParams {
     float sigma; uint32_t seed;         // noise model for the culled bins
     unsigned long long* hist;           // level-1 histogram of |dre| or null
     int chunks;
+    double* im_partials;                // role a (im != null) or null: [grid] sum w (Im written)^2
 };
 template <class Ex>
 SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
@@ -2361,7 +2423,8 @@ SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
         ex.each(st, [&](int tid, EmptyState&) { for (int b = tid; b < HIST1_BINS; b += nt) lh[b] = 0; });
         ex.sync();
     }
-    ex.each(st, [&](int tid, EmptyState&) {
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double imacc = 0.0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
         for (int c = 0; c < p.chunks; ++c) {
             const size_t qi = start + (size_t)c * nt + tid;
@@ -2388,7 +2451,15 @@ SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
                 for (int e = 0; e < 4; ++e)
                     if (e < n) ex.lds_atomic_add(&lh[(f2u(r[e]) & 0x7fffffffu) >> 20], weight_at(wr, i0 + e));
             }
+            if (p.im_partials) {
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < n) q += (float)weight_at(wr, i0 + e) * im[e] * im[e];
+                imacc += q;
+            }
         }
+        s.red[0] = imacc;
     });
     if (p.hist) {
         ex.sync();
@@ -2398,6 +2469,10 @@ SM_HD void k_spec_rescale(Ex& ex, const SpecRescaleParams& p) {
                 if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
             }
         });
+    }
+    if (p.im_partials) {
+        ex.sync();
+        ex.template block_sum<1>(st, [&](const double* tot) { p.im_partials[ex.bid()] = tot[0]; });
     }
 }
 

@@ -148,6 +148,8 @@ SM_KERNEL_TAG(KCorrPartial, CorrPartialParams, "correlate_pairs", k_corr_partial
 SM_KERNEL_TAG(KCorrFinish, CorrFinishParams, "correlate_finish", k_corr_finish(ex, p))
 SM_KERNEL_TAG(KSerialNorm, SerialNormParams, "serial_norm", k_serial_norm(ex, p))
 SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
+SM_KERNEL_TAG(KSumsqCand, SumsqCandParams, "spec_norm_cand", k_sumsq_cand(ex, p))
+SM_KERNEL_TAG(KSumSpec, SumSpecParams, "spec_norm_sum", k_sum_spec(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
 
 // ---- FFT planner ---------------------------------------------------------------
@@ -219,6 +221,7 @@ class Pipeline {
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
+    bool fuse_spec_norm = true;       // their Parseval norm comes out of the cull selection and the role-a column pass
     float noise_sigma = 1.2e-7f;      // rounding-noise model for their culled bins (k_spec_rescale)
 
     explicit Pipeline(int device) : be(device) {}
@@ -366,7 +369,9 @@ class Pipeline {
     static constexpr size_t OFF_NORM2 = OFF_FLAGS + 64;                    // double[2]
     static constexpr size_t OFF_PART = OFF_NORM2 + 64;                     // double partials
     static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
-    static constexpr size_t SMALL_BYTES = OFF_PART + PART_DOUBLES * 8;
+    static constexpr size_t OFF_PART_IM = OFF_PART + PART_DOUBLES * 8;     // sum w (Im a)^2 partials of the role-a producer
+    static constexpr size_t PART_IM_DOUBLES = 131072;
+    static constexpr size_t SMALL_BYTES = OFF_PART_IM + PART_IM_DOUBLES * 8;
     unsigned long long* d_hist() { return (unsigned long long*)((char*)small_.p + OFF_HIST); }
     unsigned long long* d_hist2() { return d_hist() + HIST1_BINS; }
     unsigned long long* d_hist3() { return d_hist2() + HIST_LO_BINS; }
@@ -384,6 +389,7 @@ class Pipeline {
     }
     double* d_norm2() { return (double*)((char*)small_.p + OFF_NORM2); }
     double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
+    double* d_part_im() { return (double*)((char*)small_.p + OFF_PART_IM); }
     // The four working planes come from a pool of equally sized buffers: a pair merge whose
     // result stays in the spectral domain (K >= 3) keeps its Re R / Im a planes as they are - the
     // planes are detached from the working set and fresh ones take their place.
@@ -536,7 +542,9 @@ class Pipeline {
         if (grid_out) *grid_out = grid * g.batch;
         return SMHIP_OK;
     }
-    int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr) {
+    // im_parts (optional, role a): the kernel also leaves sum w (Im a)^2 per work-group in d_part_im();
+    // *im_parts = how many
+    int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr, int* im_parts = nullptr) {
         F2SParams p;
         const int Rt = g.R / g.fold;                 // transform length (R2 on the folded path)
         int rc = get_plan(Rt, p.plan);
@@ -552,12 +560,16 @@ class Pipeline {
         const int xg = G >= 8 ? 1 : 8 / G;
         const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
+        const bool want_im = im_parts && role_a && (size_t)grid * g.batch <= PART_IM_DOUBLES;
+        if (im_parts) *im_parts = want_im ? grid * g.batch : -1;
+        p.im_partials = want_im ? d_part_im() : nullptr;
         if (g.fold == 4) { launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p); return SMHIP_OK; }
         const cf4* const t1base = p.t1;
         const size_t pslice = (size_t)(g.C / 2 + 1) * g.R;              // plane floats per slice
         for (int bi = 0; bi < g.batch; ++bi) {
             p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
             p.re = plane(g, role_a ? P_REA : P_REB) + bi * pslice; p.im = plane(g, P_IMA) + bi * pslice;
+            p.im_partials = want_im ? d_part_im() + (size_t)bi * grid : nullptr;
             launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
         }
         return SMHIP_OK;
@@ -582,7 +594,8 @@ class Pipeline {
         be.sync(stream);
         sre = mail_->norm2[0]; sim = mail_->norm2[1];
     }
-    void run_spec_rescale(const Geo& g, const float* re, const float* im, float thr, float scale, bool role_a, bool hist) {
+    void run_spec_rescale(const Geo& g, const float* re, const float* im, float thr, float scale, bool role_a, bool hist,
+                          int* im_parts = nullptr) {
         const size_t total = (size_t)g.Cb * g.R;
         SpecRescaleParams q;
         q.re = re; q.im = role_a ? im : nullptr;
@@ -591,7 +604,28 @@ class Pipeline {
         q.thr = thr; q.scale = scale; q.sigma = noise_sigma; q.seed = ++noise_seed_;
         q.hist = hist ? d_hist() : nullptr;
         q.chunks = pick_chunks((total + 3) / 4, 256, 8, 8);
-        be.template launch<KSpecRescale>(stream_grid((total + 3) / 4, 256, q.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, q, stream);
+        const int grid = stream_grid((total + 3) / 4, 256, q.chunks);
+        const bool want_im = im_parts && role_a && (size_t)grid <= PART_IM_DOUBLES;
+        if (im_parts) *im_parts = want_im ? grid : -1;
+        q.im_partials = want_im ? d_part_im() : nullptr;
+        be.template launch<KSpecRescale>(grid, 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, q, stream);
+    }
+    // the Parseval sums of a pair result that stays spectral, WITHOUT a pass of their own: sum w Re R_c^2
+    // came out of the cull selection pass (`sel_parts` work-groups, + the candidates settled here), sum w
+    // Im a^2 out of the role-a producer (`im_parts`).  One sync, as run_spec_norm.
+    void run_spec_norm_fused(int sel_parts, int im_parts, double& sre, double& sim) {
+        SumsqCandParams sc;
+        sc.cand = cand_lists(); sc.thr = d_thr(1); sc.partials = d_part() + 4 * (size_t)sel_parts;
+        be.template launch<KSumsqCand>(CAND_GRID, 256, LDS_SCRATCH_FLOATS * 4, sc, stream);
+        SumSpecParams sp;
+        sp.part4 = d_part(); sp.n4 = sel_parts + CAND_GRID; sp.part1 = d_part_im(); sp.n1 = im_parts; sp.out = mail_->norm2;
+        sp.zero_u32 = d_candctr(); sp.zero_u32_count = 3;
+        be.template launch<KSumSpec>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        PublishParams pp;
+        pp.flags = d_flags(); pp.thr = d_thr(0); pp.consts = d_consts(); pp.mail = mail_; pp.zero_flags = nullptr;
+        be.template launch<KPublish>(1, 64, LDS_SCRATCH_FLOATS * 4, pp, stream);
+        be.sync(stream);
+        sre = mail_->norm2[0]; sim = mail_->norm2[1];
     }
 
     void read_norms(int grid, double& na, double& nb) {
@@ -659,7 +693,7 @@ class Pipeline {
     // safe_select = true: three plain histogram passes, one scan after each.
     static constexpr int CAND_GRID = 256;
     void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out,
-                    bool fuse_reduce = false, int* nparts_out = nullptr) {
+                    bool fuse_reduce = false, int* nparts_out = nullptr, bool sumsq = false) {
         const size_t total = (size_t)g.Cb * g.R;
         HistParams h;
         h.X = X; h.Y = Y; h.R = g.R; h.C = g.Cw; h.Cb = g.Cb; h.vec4 = vec4(g); h.sel = d_sel(0);
@@ -688,6 +722,7 @@ class Pipeline {
         q.X = X; q.Y = Y; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0);
         q.hist1 = d_hist(); q.rank = rank; q.hist = d_hist2();
         q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part();
+        q.sumsq = (sumsq && !Y) ? 1 : 0;
         q.flush_always = debug_flush_always ? 1 : 0;
         q.chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, 4);   // 4 resident work-groups per CU (113 VGPRs): one round, no tail
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
@@ -703,9 +738,10 @@ class Pipeline {
         s.zero_also = d_hist(); s.zero_count = HIST1_BINS + HIST_LO_BINS;      // hist1 and hist2 (hist3 is s.hist)
         // the list counters are cleared by the last kernel that reads them: this scan, or (when
         // the slerp sums come from the lists) slerp_consts after the candidate reduction
-        if (!q.fuse_reduce) { s.zero_u32 = d_candctr(); s.zero_u32_count = 3; }   // not the sticky overflow word
+        if (!q.fuse_reduce && !q.sumsq) { s.zero_u32 = d_candctr(); s.zero_u32_count = 3; }   // not the sticky overflow word
         be.template launch<KScan>(1, 256, scan_lds, s, stream);
 
+        if (q.sumsq && nparts_out) *nparts_out = grid2;          // run_spec_norm_fused() finishes (and clears the counters)
         if (q.fuse_reduce) {
             ReduceCandParams rc;
             rc.cand = q.cand; rc.thr = thr_out; rc.partials = d_part() + 4 * (size_t)grid2;
@@ -845,7 +881,7 @@ class Pipeline {
     // spectrum-domain part of a pair merge; planes P_REA/P_IMA/P_REB already hold
     // the (scaled) half spectra.  Leaves Re R in P_RER and the cull threshold in d_thr(1).
     void spectral_blend(const Geo& g, int mode, double t, double t_sum, double cutoff_pct, double cull_pct,
-                        int agreement, bool level1_hist_done, bool& have_cull) {
+                        int agreement, bool level1_hist_done, bool& have_cull, int* sumsq_parts = nullptr) {
         const unsigned long long nfull = (unsigned long long)g.R * g.C * (unsigned long long)g.batch;
         have_cull = false;
         if (mode == BLEND_SLERP) {
@@ -856,8 +892,10 @@ class Pipeline {
                            true, &fused);
             run_slerp_consts(g, have_cut, (float)t, fused);
             run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
+            if (sumsq_parts) *sumsq_parts = 0;
             if (cull_pct > 0) {
-                run_select(g, plane(g, P_RER), nullptr, pct_index(nfull, cull_pct), true, d_thr(1));
+                run_select(g, plane(g, P_RER), nullptr, pct_index(nfull, cull_pct), true, d_thr(1), false, sumsq_parts,
+                           sumsq_parts != nullptr);
                 have_cull = true;
             }
         } else {
@@ -1366,6 +1404,7 @@ class Pipeline {
                             run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
                         }
                     } else {
+                        int im_parts = -1;
                         const bool any_spec = stack[x].spectral || stack[y].spectral ||
                                               (stack[x].rows_id >= 0 && stack[y].rows_id >= 0);
                         if (!any_spec) {
@@ -1382,23 +1421,28 @@ class Pipeline {
                             // at least one input stayed in the spectral domain: bring each input's
                             // planes in on its own (the level-1 histogram accumulates over both)
                             f1_ready = false;
+                            int* imp = (!last_round && spectral_ok && fuse_spec_norm) ? &im_parts : nullptr;
                             for (int side = 0; side < 2; ++side) {
                                 const Slot& in = side == 0 ? stack[x] : stack[y];
                                 const bool role_a = (side == 0) != swapped;
+                                int* ip = role_a ? imp : nullptr;
                                 if (in.spectral) {
                                     run_spec_rescale(g, (const float*)pool_[in.re_id].p, (const float*)pool_[in.im_id].p, in.thr,
-                                                     (float)in.spec_scale, role_a, d.cutoff_pct > 0);
+                                                     (float)in.spec_scale, role_a, d.cutoff_pct > 0, ip);
                                 } else if (in.rows_id >= 0) {
                                     if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0,
-                                                      rowspec_[in.rows_id].p))) return rc;
+                                                      rowspec_[in.rows_id].p, ip))) return rc;
                                 } else {
                                     if ((rc = run_f1_rowpairs(g, in.sig))) return rc;
-                                    if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0))) return rc;
+                                    if ((rc = run_f2s(g, role_a, (float)(1.0 / (double)(float)in.norm), d.cutoff_pct > 0, nullptr, ip))) return rc;
                                 }
                             }
                         }
                         bool have_cull;
-                        spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull);
+                        int sel_parts = 0;
+                        const bool fused_norm = im_parts > 0 && !safe_select && cull_pct > 0;
+                        spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull,
+                                       fused_norm ? &sel_parts : nullptr);
                         for (int side = 0; side < 2; ++side) {          // consumed spectral inputs give their planes back
                             Slot& in = side == 0 ? stack[x] : stack[y];
                             if (in.spectral) { pool_release(in.re_id); pool_release(in.im_id); in.re_id = in.im_id = -1; }
@@ -1406,7 +1450,8 @@ class Pipeline {
                         if (!last_round && spectral_ok) {
                             // the result stays spectral: its norm by Parseval, its planes detached
                             double sre, sim;
-                            run_spec_norm(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, sre, sim);
+                            if (fused_norm && sel_parts > 0) run_spec_norm_fused(sel_parts, im_parts, sre, sim);
+                            else run_spec_norm(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, sre, sim);
                             read_blend_info(&info, d.cutoff_pct > 0, have_cull, true, /*published=*/true);
                             const double ssum = (sre + sim) / ((double)R * (double)C);     // Parseval per [R x C] transform (slices add up)
                             out_spectral = true;

@@ -304,12 +304,20 @@ def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(en
     n_pairs = k - 1
     assert tab_m["i2_rows_inv"][0] == n_pairs and "spec_rescale" not in tab_m
     assert tab_s["i2_rows_inv"][0] == 1 and tab_s["i1_cols_inv"][0] == 1          # only the final inverse
-    assert tab_s["spec_norm"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
+    # its Parseval norm comes out of the cull selection pass and the role-a column pass: no pass of its own
+    assert "spec_norm" not in tab_s and tab_s["spec_norm_sum"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
     # every raw delta's rows are transformed once, alone (the norms come with it: no delta_norms pass),
     # and its column pass runs when the pairing has placed it
     assert tab_s["f1_rows_fwd"][0] == k and tab_s["f2s_cols_fwd1"][0] == k
     assert "f2_cols_fwd" not in tab_s and "delta_norms" not in tab_s
     assert rep_s.branches == rep_m.branches
+    # the fused norm equals the separate Parseval pass (same sums, other association)
+    engine.ctx.debug_option("fuse_spec_norm", 0)
+    try:
+        out_u, rep_u, delta_u = engine.merge_layer(fts, bases, alphas, bo, want_delta=True)
+    finally:
+        engine.ctx.debug_option("fuse_spec_norm", 1)
+    assert float((delta_u.cpu() - delta_s).abs().max()) <= 2e-6 * float(delta_s.abs().max())
     floor = golden.manifest["layer_self_floor"][cid]
     from oracle import spectral_oracle as so
     assert so.rel_err(out_s.float(), out_m.float()) <= 2.0 * floor
