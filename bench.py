@@ -110,7 +110,7 @@ def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
             "f2_cols_fwd": 0.0,                            # (the fused two-signal column pass is K = 2's)
             "f2s_cols_fwd1": k * 7.0,                      # 4n in + Re, Im out (role a) or Re out (role b)
             "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
-            "spec_norm": inter * 4.0,                      # Re R + Im a
+            "spec_norm": inter * 4.0,                      # Re R + Im a (fallback: normally fused into select_lvl2 / f2s)
             "spec_rescale": inter * 4.0,                   # role b: Re in, Re out (role a: 8n)
             "select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs,
         }
