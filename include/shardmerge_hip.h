@@ -158,7 +158,8 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
 
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
  *      lists (0 = default) so that the overflow fallback can be exercised;
- *      "sel_chunks" sets the steps per thread of the level-2 selection pass and
+ *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
+ *      "sel_wgs_per_cu" the resident work-groups per CU its grid is sized for (0 = default 5), and
  *      "sel_flush_always" flushes its staged candidates after every round (the
  *      mid-stream flush that only very large tensors reach otherwise);
  *      "spectral_intermediates" = 0 makes a K >= 3 tournament materialise every intermediate

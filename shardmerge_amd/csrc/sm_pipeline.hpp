@@ -219,6 +219,7 @@ class Pipeline {
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
+    int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
     bool fuse_spec_norm = true;       // their Parseval norm comes out of the cull selection and the role-a column pass
@@ -724,7 +725,7 @@ class Pipeline {
         q.cand = cand_lists(); q.fuse_reduce = (fuse_reduce && Y) ? 1 : 0; q.partials = d_part();
         q.sumsq = (sumsq && !Y) ? 1 : 0;
         q.flush_always = debug_flush_always ? 1 : 0;
-        q.chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, 4);   // 4 resident work-groups per CU (113 VGPRs): one round, no tail
+        q.chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, sel_wgs_per_cu);   // resident work-groups per CU: one round, no tail
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
         while ((size_t)(grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
         const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);
