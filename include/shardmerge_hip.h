@@ -29,7 +29,7 @@ typedef struct smhip_ctx smhip_ctx;
 enum {
     SMHIP_OK = 0,
     SMHIP_ERR_HIP = 1,         /* a HIP runtime call failed */
-    SMHIP_ERR_SHAPE = 2,       /* unsupported shape (length with a prime factor > 13, or > 32768) */
+    SMHIP_ERR_SHAPE = 2,       /* unsupported shape, see smhip_length_supported / smhip_shape_supported */
     SMHIP_ERR_INF_IFFT = 3,    /* "Inf in ifft output"            (functions.py:215-217) */
     SMHIP_ERR_INF_MERGED = 4,  /* "Inf in merged tensor for ..."  (fast_fourier.py:273-274) */
     SMHIP_ERR_ARG = 5,
@@ -55,8 +55,14 @@ const char* smhip_version(void);
 /* pre-size the workspace for [rows x cols] tensors (optional; it grows on demand) */
 int smhip_reserve(smhip_ctx* ctx, int rows, int cols);
 size_t smhip_workspace_bytes(smhip_ctx* ctx);
-/* 0 if a length-n transform is supported, SMHIP_ERR_SHAPE otherwise */
+/* 0 if a length-n transform has a work-group plan (n <= 32768 with prime factors <= 13; what the
+ * function-level entry points A4-A10 need of both lengths), SMHIP_ERR_SHAPE otherwise */
 int smhip_length_supported(int n);
+/* 0 if smhip_merge_layer takes a [rows x cols] tensor (rows = 1 for 1-D): one length must have a
+ * plan; the other may also be p * M with M planned and even and p <= 256 - 11008 = 43 * 256,
+ * 18944 = 37 * 512, 65536 = 2 * 32768, 128256 = 167 * 768 - which costs one extra pass over the
+ * row spectra each way (and, when it is the ROW length, a transpose of the operands). */
+int smhip_shape_supported(int rows, int cols);
 
 /* ---- A4 / A8: transforms (reference fft_transform / ifft_transform,
  *      functions.py:45-73).  x: device float[rows*cols] (rows = 1 for 1-D);
@@ -159,6 +165,8 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
  *      lists (0 = default) so that the overflow fallback can be exercised;
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
+ *      "force_split" = p splits the column length of smhip_merge_layer into p row blocks (the path of
+ *      lengths without a plan, smhip_shape_supported) although it has one, 0 = off;
  *      "sel_wgs_per_cu" the resident work-groups per CU its grid is sized for (0 = default 5), and
  *      "sel_flush_always" flushes its staged candidates after every round (the
  *      mid-stream flush that only very large tensors reach otherwise);

@@ -88,6 +88,7 @@ class SmhipLibrary:
         d.smhip_workspace_bytes.argtypes = [P]
         d.smhip_workspace_bytes.restype = C.c_size_t
         d.smhip_length_supported.argtypes = [I]
+        d.smhip_shape_supported.argtypes = [I, I]
         d.smhip_fft_transform.argtypes = [P, P, I, I, P, P]
         d.smhip_ifft_transform.argtypes = [P, P, I, I, P, P]
         d.smhip_interpolate_fft_components.argtypes = [P, P, P, I, I, D, D, D, D, I, P, C.POINTER(BlendInfo), P]
@@ -109,6 +110,10 @@ class SmhipLibrary:
 
     def length_supported(self, n: int) -> bool:
         return self.dll.smhip_length_supported(int(n)) == OK
+
+    def shape_supported(self, rows: int, cols: int) -> bool:
+        """what merge_layer takes: one length planned, the other planned or p * M (include/shardmerge_hip.h)"""
+        return self.dll.smhip_shape_supported(int(rows), int(cols)) == OK
 
 
 class Context:

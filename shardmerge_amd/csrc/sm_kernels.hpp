@@ -3123,4 +3123,126 @@ SM_HD void k_cull(Ex& ex, const CullParams& p) {
     });
 }
 
+
+// =====================================================================
+// Long / rough column lengths: R = p * M with M a length the work-group engine plans
+// (even) and p <= DFTP_MAX_P anything (43 for the 11008 of Llama-2-7B, 37 for the 18944 of
+// Qwen2-7B, 2 for 65536 ...).  Decimation in frequency with n = n1 + M n2, k = p k1 + k2:
+//
+//     X[p k1 + k2] = sum_n1 W_M^(n1 k1) * { W_R^(n1 k2) * sum_n2 W_p^(n2 k2) x[n1 + M n2] }
+//
+// so the p row BLOCKS [n2 M, (n2+1) M) are first combined by a p-point DFT (this kernel, in
+// place on the row pass's output T1, with the W_R twiddle), and block k2 then goes through
+// the ordinary M-point column pass - the pipeline treats the tensor as p slices of M rows
+// (the `batch` machinery) whose planes hold the bins k = p k1 + k2 of slice k2.  The inverse
+// runs the other way round: M-point inverse column passes per slice, then the conjugate
+// twiddle and the inverse p-point DFT across the slices of G, then the inverse row pass.
+// The direct p-point sums cost O(p) per element: HBM-bound up to p ~ 16, ALU-bound beyond.
+// =====================================================================
+constexpr int DFTP_MAX_P = 256;
+constexpr int DFTP_COLS = 16;          // bin columns per work-group: 16 x 16 B = 256 contiguous bytes
+struct DftpParams {
+    cf4* buf;              // T1 (forward) or G (inverse): p slices
+    const cf2* tw;         // tw[j] = exp(-2 pi i j / (p M)), j < p M
+    int p, M;
+    int units;             // row units per slice: M (a cf4 = signals a, b of one row) or M / 2 (rowpair)
+    int rowpair;           // 1: a cf4 = rows 2u, 2u + 1 of ONE signal (their twiddles differ)
+    int ilv;               // rows interleaved in groups of ilv (T1 of the two-signal row pass)
+    int pitch;             // cf4 per row unit
+    int ncols;             // valid bin columns
+    size_t slice_stride;   // cf4 between slices
+    int inverse;
+};
+SM_HD cf2 cmul(cf2 a, cf2 b) { cf2 r = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; return r; }
+template <class Ex>
+SM_HD void k_dftp(Ex& ex, const DftpParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    cf4* tile = (cf4*)(ex.lds() + LDS_SCRATCH_FLOATS);             // [p][DFTP_COLS]
+    cf2* wp = (cf2*)(tile + (size_t)p.p * DFTP_COLS);               // W_p^j (conjugated for the inverse)
+    const int ntiles = (p.ncols + DFTP_COLS - 1) / DFTP_COLS;
+    const int u = ex.bid() / ntiles, c0 = (ex.bid() % ntiles) * DFTP_COLS;
+    if (u >= p.units) return;
+    const int n1a = p.rowpair ? 2 * u : u, n1b = p.rowpair ? 2 * u + 1 : u;
+    const size_t row_off = ((size_t)(u / p.ilv) * p.pitch) * p.ilv + u % p.ilv;
+    const float sgn_im = p.inverse ? -1.f : 1.f;
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int j = tid; j < p.p; j += nt) { cf2 w = p.tw[(size_t)j * p.M]; w.y *= sgn_im; wp[j] = w; }
+        for (int idx = tid; idx < p.p * DFTP_COLS; idx += nt) {
+            const int s = idx / DFTP_COLS, c = c0 + idx % DFTP_COLS;
+            cf4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < p.ncols) {
+                v = p.buf[(size_t)s * p.slice_stride + row_off + (size_t)c * p.ilv];
+                if (p.inverse) {                   // conjugate twiddle first: slice index s is k2
+                    cf2 wa = p.tw[(size_t)n1a * s], wb = p.tw[(size_t)n1b * s];
+                    wa.y = -wa.y; wb.y = -wb.y;
+                    const cf2 a = cmul({v.x, v.y}, wa), b = cmul({v.z, v.w}, wb);
+                    v = {a.x, a.y, b.x, b.y};
+                }
+            }
+            tile[idx] = v;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int idx = tid; idx < p.p * DFTP_COLS; idx += nt) {
+            const int k = idx / DFTP_COLS, cl = idx % DFTP_COLS, c = c0 + cl;
+            if (c >= p.ncols) continue;
+            float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
+            int wi = 0;
+            for (int s = 0; s < p.p; ++s) {
+                const cf4 v = tile[s * DFTP_COLS + cl];
+                const cf2 w = wp[wi];
+                ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
+                br += v.z * w.x - v.w * w.y; bi += v.z * w.y + v.w * w.x;
+                wi += k; if (wi >= p.p) wi -= p.p;
+            }
+            cf2 a = {ar, ai}, b = {br, bi};
+            if (!p.inverse) {                      // slice index k is k2
+                a = cmul(a, p.tw[(size_t)n1a * k]); b = cmul(b, p.tw[(size_t)n1b * k]);
+            }
+            cf4 o = {a.x, a.y, b.x, b.y};
+            p.buf[(size_t)k * p.slice_stride + row_off + (size_t)c * p.ilv] = o;
+        }
+    });
+}
+
+// [R][C] -> [C][R], elements of 2 or 4 bytes moved as bits (32 x 32 tiles through LDS): a tensor
+// whose ROW length is the rough one is merged transposed (fft2 commutes with the transpose and
+// every statistic of the merge is a sum or an order statistic over all bins)
+constexpr int TR_TILE = 32;
+struct TransposeParams { const void* src; void* dst; int R, C; int esize; };
+template <class Ex>
+SM_HD void k_transpose(Ex& ex, const TransposeParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    uint32_t* tile = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);   // [32][33]
+    const int tc = (p.C + TR_TILE - 1) / TR_TILE;
+    const int r0 = (ex.bid() / tc) * TR_TILE, c0 = (ex.bid() % tc) * TR_TILE;
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int idx = tid; idx < TR_TILE * TR_TILE; idx += nt) {
+            const int r = r0 + idx / TR_TILE, c = c0 + idx % TR_TILE;
+            uint32_t v = 0;
+            if (r < p.R && c < p.C) {
+                const size_t i = (size_t)r * p.C + c;
+                v = p.esize == 4 ? ((const uint32_t*)p.src)[i] : (uint32_t)((const uint16_t*)p.src)[i];
+            }
+            tile[(idx / TR_TILE) * (TR_TILE + 1) + idx % TR_TILE] = v;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int idx = tid; idx < TR_TILE * TR_TILE; idx += nt) {
+            const int c = c0 + idx / TR_TILE, r = r0 + idx % TR_TILE;
+            if (r < p.R && c < p.C) {
+                const uint32_t v = tile[(idx % TR_TILE) * (TR_TILE + 1) + idx / TR_TILE];
+                const size_t o = (size_t)c * p.R + r;
+                if (p.esize == 4) ((uint32_t*)p.dst)[o] = v; else ((uint16_t*)p.dst)[o] = (uint16_t)v;
+            }
+        }
+    });
+}
+
 }  // namespace smhip

@@ -55,7 +55,8 @@ SM_FFT_KERNEL_TAG(KI1x1Q, I1Params, "i1_cols_inv", (k_i1<P, 1, true>(ex, p)), 1,
 SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(ex, p)), i1_bins<P>(), 4)
 
 // lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
-// and the 3/5/7 * 2^k hidden and MLP sizes of other common models: a run-time planned length
+// the 3/5/7 * 2^k hidden and MLP sizes of other common models, and 256 / 512: the row blocks of the
+// split column lengths 11008 = 43 * 256 (Llama-2-7B) and 18944 = 37 * 512 (Qwen2-7B): a run-time planned length
 // runs the same code with its register arrays in scratch memory, 5120^2: 5.4 ms against 0.7);
 // must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
@@ -95,7 +96,9 @@ SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(
     X(SPlan<12288, 512, false, 4, 16, 16, 16, 3>)  \
     X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>) \
     X(SPlan<27648, 1024, false, 4, 32, 32, 3, 3, 3>) \
-    X(SPlan<2304, 128, false, 4, 16, 16, 3, 3>)
+    X(SPlan<2304, 128, false, 4, 16, 16, 3, 3>) \
+    X(SPlan<256, 64, false, 4, 16, 16>)            \
+    X(SPlan<512, 64, false, 4, 32, 16>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
 // 1.6x slower than split exchanges, so no plan uses it for now
@@ -151,6 +154,8 @@ SM_KERNEL_TAG(KSpecNorm, SpecNormParams, "spec_norm", k_spec_norm(ex, p))
 SM_KERNEL_TAG(KSumsqCand, SumsqCandParams, "spec_norm_cand", k_sumsq_cand(ex, p))
 SM_KERNEL_TAG(KSumSpec, SumSpecParams, "spec_norm_sum", k_sum_spec(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
+SM_KERNEL_TAG(KDftp, DftpParams, "dft_across_slices", k_dftp(ex, p))
+SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
 
 // ---- FFT planner ---------------------------------------------------------------
 struct HostPlan {
@@ -193,6 +198,31 @@ inline bool plan_shape(int N, int& T, std::vector<int>& radices) {
     return false;
 }
 
+// A column length the engine cannot plan (a prime factor > 13, or > 32768): R = p * M with M
+// planned and even, p <= DFTP_MAX_P as small as possible (k_dftp).  p = 1: plain plan.
+inline bool rough_split(int N, int& p, int& M) {
+    int T;
+    std::vector<int> rad;
+    if (plan_shape(N, T, rad)) { p = 1; M = N; return true; }
+    for (p = 2; p <= DFTP_MAX_P; ++p) {
+        if (N % p) continue;
+        M = N / p;
+        if (M % 2 == 0 && plan_shape(M, T, rad)) return true;
+    }
+    return false;
+}
+// [rows x cols] as the layer merge takes it: the row length must be planned; the column length may
+// be split (rough_split); a tensor that fits only the other way round is merged transposed
+inline int shape_support(int rows, int cols, bool* transposed = nullptr) {
+    int T, p, M;
+    std::vector<int> rad;
+    if (transposed) *transposed = false;
+    if (rows < 1 || cols < 1) return 0;
+    if (plan_shape(cols, T, rad) && rough_split(rows, p, M)) return 1;
+    if (plan_shape(rows, T, rad) && rough_split(cols, p, M)) { if (transposed) *transposed = true; return 1; }
+    return 0;
+}
+
 struct Buffer {
     void* p = nullptr;
     size_t cap = 0;
@@ -219,6 +249,7 @@ class Pipeline {
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
+    int debug_force_split = 0;        // test hook: split a column length into this many row blocks even if it has a plan
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
@@ -233,6 +264,8 @@ class Pipeline {
         if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
         for (Buffer& b : rowspec_) if (b.p) be.free(b.p);
+        for (Buffer& b : tr_) if (b.p) be.free(b.p);
+        for (auto& kv : rough_tw_) if (kv.second) be.free(kv.second);
     }
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
@@ -266,8 +299,9 @@ class Pipeline {
             it = plans_.emplace(N, hp).first;
         }
         if (!it->second.ok) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "unsupported transform length %d (needs factors in {2,3,5,7,11,13} and <= %d)", N, EMAX * 1024);
+            char buf[256];
+            snprintf(buf, sizeof buf, "unsupported transform length %d (a row length needs factors in {2,3,5,7,11,13} and <= %d; the layer merge "
+                                       "also takes p * M column lengths, p <= %d)", N, EMAX * 1024, DFTP_MAX_P);
             return fail(SMHIP_ERR_SHAPE, buf);
         }
         out = it->second.dev;
@@ -288,6 +322,7 @@ class Pipeline {
         for (const Buffer& b : inter_) t += b.cap;
         for (const Buffer& b : rowspec_) t += b.cap;
         for (const Buffer& b : pool_) t += b.cap;
+        for (const Buffer& b : tr_) t += b.cap;
         return t;
     }
 
@@ -301,6 +336,8 @@ class Pipeline {
                                   // over everything (the reference: fftn(dim=(-2,-1)), functions.py:58); Cb then
                                   // counts the bin columns of ALL slices (the planes hold them one after the other)
         size_t t1_slice;          // float4 of T1 per slice
+        int rough;                // > 1: the `batch` slices are the row blocks of ONE [rough * R x C] tensor whose column
+                                  // length the engine cannot plan; k_dftp combines them (see there)
     };
     // shapes whose column pass runs folded: a long column (its own plan needs >= 512 threads per
     // transform) over rows short enough for four of them to share a work-group
@@ -327,6 +364,7 @@ class Pipeline {
         g.ilv = t1_interleave(R);
         g.plane_floats = round_up((size_t)g.Cb * R, 64);
         g.Cw = full ? -1 : C;
+        g.rough = 1;
         return g;
     }
     // rows interleaved in the forward intermediate T1: the column pass then reads ilv*16
@@ -454,6 +492,37 @@ class Pipeline {
     static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
     static int vec4(const Geo& g) { return g.full ? (((size_t)g.R * g.C) % 4 == 0) : (g.R % 4 == 0); }
 
+    // exp(-2 pi i j / N) for a length without a plan (k_dftp's twiddles)
+    int rough_twiddles(int N, const cf2** out) {
+        auto it = rough_tw_.find(N);
+        if (it == rough_tw_.end()) {
+            std::vector<cf2> tw(N);
+            for (int j = 0; j < N; ++j) {
+                const double ang = -2.0 * M_PI * (double)j / (double)N;
+                tw[j].x = (float)cos(ang); tw[j].y = (float)sin(ang);
+            }
+            void* d = be.alloc(sizeof(cf2) * N);
+            if (!d) return fail(SMHIP_ERR_NOMEM, "twiddle alloc failed");
+            be.h2d(d, tw.data(), sizeof(cf2) * N, stream);
+            be.sync(stream);                       // the host vector dies here
+            it = rough_tw_.emplace(N, d).first;
+        }
+        *out = (const cf2*)it->second;
+        return SMHIP_OK;
+    }
+    // the p-point DFT across the slices of a rough-length tensor, in place on T1 / G
+    int run_dftp(const Geo& g, void* buf, bool rowpair, int ilv, int pitch, size_t slice_stride, bool inverse) {
+        DftpParams q;
+        int rc = rough_twiddles(g.R * g.rough, &q.tw);
+        if (rc) return rc;
+        q.buf = (cf4*)buf; q.p = g.rough; q.M = g.R; q.units = rowpair ? g.R / 2 : g.R; q.rowpair = rowpair ? 1 : 0;
+        q.ilv = ilv; q.pitch = pitch; q.ncols = g.C / 2 + 1; q.slice_stride = slice_stride; q.inverse = inverse ? 1 : 0;
+        const int ntiles = (q.ncols + DFTP_COLS - 1) / DFTP_COLS;
+        const size_t lds = LDS_SCRATCH_FLOATS * 4 + (size_t)q.p * DFTP_COLS * sizeof(cf4) + (size_t)q.p * sizeof(cf2);
+        be.template launch<KDftp>(q.units * ntiles, 256, lds, q, stream);
+        return SMHIP_OK;
+    }
+
     // F1: T1 <- row spectra of (a, b); per-group sums of squares land in d_part()
     int run_f1(const Geo& g, const SigDesc& a, const SigDesc& b, int& grid_out) {
         F1Params p;
@@ -478,16 +547,22 @@ class Pipeline {
             return SMHIP_OK;
         }
         const int xg = p.ilv > p.nb ? p.ilv / p.nb : 1;
-        const int grid = (int)round_up((size_t)(g.R + p.nb - 1) / p.nb, 8 * xg);
-        if ((size_t)grid * 2 * g.batch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        // the row blocks of a split column length are one tensor: their rows go in one launch when the
+        // blocks lie back to back in T1
+        const bool joint = joint_rows(g);
+        const int nlaunch = joint ? 1 : g.batch;
+        if (joint) p.R = g.R * g.rough;
+        const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8 * xg);
+        if ((size_t)grid * 2 * nlaunch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
-        for (int bi = 0; bi < g.batch; ++bi) {          // one launch per slice of a rank > 2 tensor
+        for (int bi = 0; bi < nlaunch; ++bi) {          // one launch per slice of a rank > 2 tensor
             p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
             p.t1 = (cf4*)t1_.p + (size_t)bi * g.t1_slice;
             p.partials = d_part() + (size_t)bi * 2 * grid;
             launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
         }
-        grid_out = grid * g.batch;
+        grid_out = grid * nlaunch;
+        if (g.rough > 1) return run_dftp(g, t1_.p, false, p.ilv, g.pitch4, g.t1_slice, false);
         return SMHIP_OK;
     }
     // ---- one signal (rounds >= 2: the pair's other input stayed spectral) ---------------------
@@ -504,6 +579,7 @@ class Pipeline {
     static size_t fold_slab_elems(const Geo& g, bool rowpair = false) {
         return round_up((size_t)g.R / (rowpair ? 8 : 4), 8) * (size_t)g.pitch4;
     }
+    static bool joint_rows(const Geo& g) { return g.rough > 1 && g.R % 16 == 0; }
     int run_f1_rowpairs(const Geo& g, const SigDesc& sig, void* t1buf = nullptr, double* partials = nullptr, int* grid_out = nullptr) {
         F1Params p;
         int rc = get_plan(g.C, p.plan);
@@ -529,18 +605,22 @@ class Pipeline {
             return SMHIP_OK;
         }
         const int xgs = p.ilv > p.nb ? p.ilv / p.nb : 1;
+        const bool joint = joint_rows(g);
+        const int nlaunch = joint ? 1 : g.batch;
+        if (joint) p.R = g.R * g.rough / 2;
         const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8 * xgs);
-        if ((size_t)grid * 2 * g.batch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
+        if ((size_t)grid * 2 * nlaunch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
         cf4* const t1base = p.t1;
         double* const pbase = p.partials;
-        for (int bi = 0; bi < g.batch; ++bi) {
+        for (int bi = 0; bi < nlaunch; ++bi) {
             p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
             p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
             p.partials = pbase + (size_t)bi * 2 * grid;
             launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
         }
-        if (grid_out) *grid_out = grid * g.batch;
+        if (grid_out) *grid_out = grid * nlaunch;
+        if (g.rough > 1) return run_dftp(g, t1base, true, F2S_ILV, g.pitch4, g.t1_slice / 2, false);
         return SMHIP_OK;
     }
     // im_parts (optional, role a): the kernel also leaves sum w (Im a)^2 per work-group in d_part_im();
@@ -804,18 +884,30 @@ class Pipeline {
         b.G = (const cf2*)t1_.p; b.pitchG = g.pitchG; b.R = g.R; b.C = g.C; b.Cb = Cb;
         b.nb = std::max(1, 256 / b.plan.T);
         b.vec = (g.C % 8 == 0) && aligned16(o.out) && aligned16(o.base);
-        b.inv_n = (float)(1.0 / ((double)g.R * (double)g.C));
+        b.inv_n = (float)(1.0 / ((double)g.R * (double)g.rough * (double)g.C));
         b.ifft_policy = o.ifft_policy;
         b.post = o.post; b.base_dtype = o.base_dtype; b.out_mode = o.out_mode;
         b.flags = d_flags();
-        const int pairs = (g.R + 1) / 2;
+        const bool joint = joint_rows(g);                 // the row blocks of a split column length: one row launch
+        if (joint) b.R = g.R * g.rough;
+        const int pairs = (b.R + 1) / 2;
         const int grid2 = (pairs + b.nb - 1) / b.nb;
-        const bool want_norm = norm_grid && (size_t)grid2 * 2 * g.batch <= PART_DOUBLES;
-        if (norm_grid) *norm_grid = want_norm ? grid2 * g.batch : -1;
+        const int nrow_launch = joint ? 1 : g.batch;
+        const bool want_norm = norm_grid && (size_t)grid2 * 2 * nrow_launch <= PART_DOUBLES;
+        if (norm_grid) *norm_grid = want_norm ? grid2 * nrow_launch : -1;
         const size_t lds2 = (LDS_SCRATCH_FLOATS + (size_t)b.nb * b.plan.lds_floats) * 4;
         const size_t pslice = (size_t)Cb * g.R, eslice = (size_t)g.R * g.C;
-        for (int bi = 0; bi < g.batch; ++bi) {            // per slice: columns, then rows (T1 is reused)
+        // a rank > 2 tensor goes slice by slice (columns, then rows; G is reused); the slices of a rough
+        // column length all run their column pass first, k_dftp combines them, then the rows
+        const int phases = g.rough > 1 ? 2 : 1;
+        for (int phase = 0; phase < phases; ++phase) {
+        if (phase == 1 && (rc = run_dftp(g, t1_.p, true, 1, g.pitchG, g.t1_slice / 2, true))) return rc;
+        for (int bi = 0; bi < g.batch; ++bi) {
+            if (g.rough > 1) { a.G = (cf2*)t1_.p + (size_t)bi * g.t1_slice; b.G = a.G; }
             a.reR = reR + bi * pslice; a.imA = imA + bi * pslice;
+            if (phases == 2 && phase == 1) {
+                // rows only
+            } else
             if (g.R == 1) {
                 be.template launch<KI1R1>(std::max(1, std::min(64, (Cb + 255) / 256)), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
             } else if (g.fold == 4) {
@@ -823,10 +915,13 @@ class Pipeline {
                 else launch_fft<KI1x1Q>(a.plan, grid1, a.plan.T, lds1, a);
             } else if (a.s >= 2) launch_fft<KI1x2>(a.plan, grid1, a.s * a.plan.T, lds1, a);
             else launch_fft<KI1x1>(a.plan, grid1, a.plan.T, lds1, a);
+            if (phases == 2 && phase == 0) continue;
+            if (joint) { if (bi > 0) break; b.G = (const cf2*)t1_.p; }
             b.base = o.base ? (const char*)o.base + bi * eslice * dt_size(o.base_dtype) : nullptr;
             b.out = (char*)o.out + bi * eslice * (o.out_mode == OUT_BF16 ? 2 : 4);
             b.norm_partials = want_norm ? d_part() + (size_t)bi * 2 * grid2 : nullptr;
             launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
+        }
         }
         return SMHIP_OK;
     }
@@ -1021,10 +1116,12 @@ class Pipeline {
 
     // ---- A10: task_arithmetic_fft2 on fp32 inputs ------------------------------------
     int pair_arith(const SigDesc& a_in, const SigDesc& b_in, int R, int C, float sa, float sb, double t, int agreement,
-                   const PairOut& po, double na_hint, double nb_hint) {
-        const Geo g = geo(R, C, false, aligned16(a_in.x) && aligned16(a_in.base) && aligned16(b_in.x) && aligned16(b_in.base) &&
-                                       aligned16(po.out) && aligned16(po.base));
-        int rc = reserve(R, C);
+                   const PairOut& po, double na_hint, double nb_hint, const Geo* layer_geo = nullptr) {
+        // (layer_geo: the layer's own geometry - slices of a rank > 2 tensor or of a rough column length)
+        const Geo g = layer_geo ? *layer_geo
+                                : geo(R, C, false, aligned16(a_in.x) && aligned16(a_in.base) && aligned16(b_in.x) && aligned16(b_in.base) &&
+                                                   aligned16(po.out) && aligned16(po.base));
+        int rc = reserve(g.R, g.C, false, g.batch);
         if (rc) return rc;
         SigDesc a = a_in, b = b_in;
         int grid;
@@ -1186,7 +1283,56 @@ class Pipeline {
     }
 
     int merge_layer(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
+        bool transposed = false;
+        if (d.k > 1 && d.batch <= 1 && shape_support(d.rows, d.cols, &transposed) && transposed)
+            return merge_layer_transposed(d, out_bf16, delta_out, rep);
         return with_select_retry([&] { return merge_layer_once(d, out_bf16, delta_out, rep); });
+    }
+    void run_transpose(const void* src, void* dst, int R, int C, int esize) {
+        TransposeParams q;
+        q.src = src; q.dst = dst; q.R = R; q.C = C; q.esize = esize;
+        const int grid = ((R + TR_TILE - 1) / TR_TILE) * ((C + TR_TILE - 1) / TR_TILE);
+        be.template launch<KTranspose>(grid, 256, LDS_SCRATCH_FLOATS * 4 + TR_TILE * (TR_TILE + 1) * 4, q, stream);
+    }
+    // The ROW length is the one without a plan, the column length has one: merge the transposed
+    // tensors ([C x R]: the rough length becomes the column length, which k_dftp handles) and
+    // transpose the result back.  fft2 commutes with the transpose, and norms, order statistics
+    // and blends do not care where a bin sits.
+    int merge_layer_transposed(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
+        if (d.k < 1 || d.k > SMHIP_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
+        const size_t n = (size_t)d.rows * d.cols;
+        std::vector<std::pair<const void*, int>> srcs;        // distinct (pointer, element size)
+        auto slot_of = [&](const void* ptr, int es) {
+            for (size_t i = 0; i < srcs.size(); ++i) if (srcs[i].first == ptr) return (int)i;
+            srcs.emplace_back(ptr, es);
+            return (int)srcs.size() - 1;
+        };
+        const int es_in = (int)dt_size(d.in_dtype), es_base = (int)dt_size(d.base_out_dtype);
+        int ft_slot[SMHIP_MAX_MODELS], base_slot[SMHIP_MAX_MODELS];
+        for (int i = 0; i < d.k; ++i) { ft_slot[i] = slot_of(d.finetune[i], es_in); base_slot[i] = slot_of(d.base[i], es_in); }
+        int bo_slot = -1;
+        for (size_t i = 0; i < srcs.size(); ++i)
+            if (srcs[i].first == d.base_out && srcs[i].second == es_base) bo_slot = (int)i;
+        if (bo_slot < 0) { srcs.emplace_back(d.base_out, es_base); bo_slot = (int)srcs.size() - 1; }
+        const size_t nsrc = srcs.size();
+        if (tr_.size() < nsrc + 2) tr_.resize(nsrc + 2);
+        int rc;
+        for (size_t i = 0; i < nsrc; ++i) {
+            if ((rc = ensure(tr_[i], n * srcs[i].second))) return rc;
+            run_transpose(srcs[i].first, tr_[i].p, d.rows, d.cols, srcs[i].second);
+        }
+        if ((rc = ensure(tr_[nsrc], n * 2))) return rc;
+        if (delta_out && (rc = ensure(tr_[nsrc + 1], n * 4))) return rc;
+        smhip_layer_desc t = d;
+        t.rows = d.cols; t.cols = d.rows;
+        for (int i = 0; i < d.k; ++i) { t.finetune[i] = tr_[ft_slot[i]].p; t.base[i] = tr_[base_slot[i]].p; }
+        t.base_out = tr_[bo_slot].p;
+        float* dt = delta_out ? (float*)tr_[nsrc + 1].p : nullptr;
+        rc = with_select_retry([&] { return merge_layer_once(t, tr_[nsrc].p, dt, rep); });
+        if (rc) return rc;
+        run_transpose(tr_[nsrc].p, out_bf16, d.cols, d.rows, 2);
+        if (delta_out) run_transpose(dt, delta_out, d.cols, d.rows, 4);
+        return SMHIP_OK;
     }
     int merge_layer_once(const smhip_layer_desc& d, void* out_bf16, float* delta_out, smhip_layer_report* rep) {
         if (d.k < 1 || d.k > SMHIP_MAX_MODELS) return fail(SMHIP_ERR_ARG, "k out of range");
@@ -1197,7 +1343,23 @@ class Pipeline {
         const size_t n = (size_t)R * C * batch;
         bool all_aligned = aligned16(d.base_out) && aligned16(out_bf16) && aligned16(delta_out);
         for (int i = 0; i < d.k; ++i) all_aligned = all_aligned && aligned16(d.finetune[i]) && aligned16(d.base[i]);
-        const Geo g = geo(R, C, false, all_aligned, batch);
+        // a column length without a plan: `rough` row blocks of Rs rows, combined by k_dftp
+        int rough = 1, Rs = R;
+        if (d.k > 1 && R > 1) {
+            if (!rough_split(R, rough, Rs) || (rough > 1 && batch > 1)) {
+                char buf[200];
+                snprintf(buf, sizeof buf, "unsupported column length %d%s (needs p * M, p <= %d, M even with factors in "
+                         "{2,3,5,7,11,13} and <= %d)", R, batch > 1 ? " for a rank > 2 tensor" : "", DFTP_MAX_P, EMAX * 1024);
+                return fail(SMHIP_ERR_SHAPE, buf);
+            }
+        }
+        if (rough == 1 && debug_force_split > 1 && batch == 1 && d.k > 1 && R % debug_force_split == 0) {
+            int T; std::vector<int> rad;
+            const int M = R / debug_force_split;
+            if (M % 2 == 0 && plan_shape(M, T, rad)) { rough = debug_force_split; Rs = M; }
+        }
+        Geo g = geo(Rs, C, false, all_aligned && rough == 1, rough > 1 ? rough : batch);
+        g.rough = rough;
         int rc;
         if (!small_.p && (rc = reserve(1, 1))) return rc;
         clear_flags();
@@ -1207,7 +1369,7 @@ class Pipeline {
         rp.merged_delta_norm = -1;
 
         const bool ref_norms = d.norm_mode == 1;       // torch's CPU norm kernel emulated for every spatial norm
-        const bool spectral_ok = spectral_inter && (R % 2 == 0) && R >= 2 && !ref_norms;   // (ref_norms needs the spatial intermediate)
+        const bool spectral_ok = spectral_inter && (Rs % 2 == 0) && Rs >= 2 && !ref_norms;   // (ref_norms needs the spatial intermediate)
         std::vector<Slot> stack(d.k);
         for (int i = 0; i < d.k; ++i) {
             stack[i].sig = SigDesc{d.finetune[i], d.base[i], d.in_dtype, 1.f};
@@ -1227,7 +1389,7 @@ class Pipeline {
             rp.delta_norm[0] = na; rp.target_norm = (double)(float)na + d.target_norm_offset; rp.merged_delta_norm = na;
             return check_flags(false, true, &rp.nan_ifft, &rp.nan_final);
         }
-        if ((rc = reserve(R, C, false, batch))) return rc;
+        if ((rc = reserve(g.R, C, false, g.batch))) return rc;
 
         // norms of every delta.  K == 2: fused into the (speculative) F1 of the only pair.
         std::vector<float> norms32(d.k);
@@ -1239,7 +1401,7 @@ class Pipeline {
             read_norms(f1_grid, na, nb);
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
-        } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(R / 2 + 8) * batch <= PART_DOUBLES &&
+        } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(g.R / 2 + 8) * g.batch <= PART_DOUBLES &&
                    rows_first(g, stack) == SMHIP_OK) {
             // K >= 3: every delta's ROWS are transformed up front, one signal at a time (row pairs);
             // the norms come with it (no separate pass over the inputs), and whichever deltas the
@@ -1372,7 +1534,7 @@ class Pipeline {
                     float* dtmp = nullptr;
                     if (last_round && delta_out) { pa = PairOut(); pa.out = delta_out; dtmp = delta_out; }
                     pa.ifft_policy = 0;
-                    if ((rc = pair_arith(A.sig, Bs.sig, R, C, (float)s, (float)(w * s), 1.0, 1, pa, na, nb))) return rc;
+                    if ((rc = pair_arith(A.sig, Bs.sig, R, C, (float)s, (float)(w * s), 1.0, 1, pa, na, nb, &g))) return rc;
                     if (dtmp) {     // add-back from the fp32 delta
                         SigDesc ds{dtmp, nullptr, DT_F32, 1.f}, none{nullptr, nullptr, DT_F32, 1.f};
                         run_combine(ds, none, 1.f, 0.f, n, nullptr, &fin, false);
@@ -1677,6 +1839,8 @@ class Pipeline {
     Mailbox* mail_ = nullptr;
     std::vector<Buffer> inter_;
     std::vector<Buffer> rowspec_;          // K >= 3: row spectra of the raw deltas (rows_first)
+    std::vector<Buffer> tr_;               // transposed copies of a layer's tensors (rough ROW length)
+    std::map<int, void*> rough_tw_;        // twiddles of the column lengths without a plan
     std::vector<double> host_part_;
 };
 

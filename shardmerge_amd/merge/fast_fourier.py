@@ -79,14 +79,21 @@ class FourierMerge(MergeTensorsBase):
             for name, rec in header.items():
                 if not name.startswith("model.layers."):
                     continue
-                for length in rec["shape"][-2:]:
-                    if length not in seen:
-                        seen[length] = lib.length_supported(int(length))
-                    if not seen[length]:
-                        bad.append(f"{name} {rec['shape']} (length {length})")
+                shape = tuple(int(v) for v in rec["shape"])
+                if not shape:
+                    continue
+                if shape not in seen:
+                    if len(shape) <= 2:
+                        rows, cols = (1, shape[0]) if len(shape) == 1 else shape
+                        seen[shape] = lib.shape_supported(rows, cols)
+                    else:       # rank > 2: slices, both lengths need a plan
+                        seen[shape] = all(lib.length_supported(v) for v in shape[-2:])
+                if not seen[shape]:
+                    bad.append(f"{name} {list(shape)}")
         if bad:
             raise NotImplementedError(
-                f"{len(bad)} block tensor(s) have a transform length the HIP library does not support, "
+                f"{len(bad)} block tensor(s) have a shape the HIP library does not support "
+                f"(include/shardmerge_hip.h, smhip_shape_supported), "
                 f"e.g. {bad[0]}; nothing was merged")
 
     def get_readme(self) -> str:

@@ -468,3 +468,117 @@ def test_correlate_pairs(engine, golden, case):
     from shardmerge_amd.tensor import functions as fn      # and the pairing that follows it
     pairs_ref = [(x, y) for x, y, _ in fn.correlated_pairs(want, "least")]
     assert [(x, y) for x, y, _ in fn.correlated_pairs(got, "least")] == pairs_ref
+
+
+def _layer_inputs(shape, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16)
+           for s_ in (0.002, 0.003, 0.0025, 0.0035)[:k]]
+    return base, fts
+
+
+@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("k", [2, 3])
+def test_column_length_without_a_plan_is_split_into_row_blocks(engine, shape, k):
+    """A column length with a prime factor > 13 (11008 = 43 * 256 of Llama-2-7B, 18944 = 37 * 512 of
+    Qwen2-7B; here 34 = 17 * 2, 136 = 17 * 8, 76 = 19 * 4, 172 = 43 * 4, 272 = 17 * 16) is merged as p row blocks of M
+    rows that k_dftp combines (sm_kernels.hpp) - same bar as any other length."""
+    from oracle import spectral_oracle as so
+    assert engine.lib.shape_supported(*shape) and not engine.lib.length_supported(shape[0])
+    base, fts = _layer_inputs(shape, k, 100 + k)
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    pc.check_layer_steps(rep, tr, out.numel())
+    if k == 2:
+        assert pc.spectral_residual(delta, tr.merged_delta)[1] < 2e-5
+        assert so.rel_err(out.float(), ref.float()) < 8.0 / (out.numel() ** 0.5)
+    else:           # K = 3: the reference's own chaos floor (DESIGN 6.2), as for any other length
+        assert so.rel_err(out.float(), ref.float()) < 5e-3 and so.rel_err(delta, tr.merged_delta) < 3e-2
+
+
+@pytest.mark.parametrize("p", [2, 4, 8])
+@pytest.mark.parametrize("k", [2, 3])
+def test_forced_split_agrees_with_the_plain_column_pass(engine, p, k):
+    """The same tensor through the plain column pass and through p row blocks + k_dftp (test hook
+    force_split; what a length > 32768 takes with p = 2): same branches, thresholds and result."""
+    from oracle import spectral_oracle as so
+    base, fts = _layer_inputs((256, 128), k, 7 + p)
+    plain = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    engine.ctx.debug_option("force_split", p)
+    try:
+        split = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+    finally:
+        engine.ctx.debug_option("force_split", 0)
+    assert split[1].branches == plain[1].branches and split[1].steps == plain[1].steps
+    a, b = split[1].infos[0], plain[1].infos[0]          # the first pair merges raw deltas: rounding-level agreement
+    assert abs(a.cutoff_threshold - b.cutoff_threshold) <= 1e-5 * abs(b.cutoff_threshold)
+    assert abs(a.cull_threshold - b.cull_threshold) <= 5e-5 * b.cull_threshold and abs(a.n_slerp - b.n_slerp) <= 4
+    if k == 2:
+        assert pc.spectral_residual(split[2], plain[2])[1] < 2e-6
+    else:
+        assert so.rel_err(split[2], plain[2]) < 3e-2           # K = 3: the chaos floor, as between any two FFTs
+
+
+@pytest.mark.parametrize("shape", [(64, 34), (96, 76), (1, 68), (128, 2 * 43)], ids=lambda s: "x".join(map(str, s)))
+def test_row_length_without_a_plan_is_merged_transposed(engine, shape):
+    """When the ROW length is the one without a plan the operands are transposed on the device, merged
+    ([C x R]: the rough length is the column length now) and the result is transposed back.  fft2
+    commutes with the transpose; the reference's result, though, depends on the orientation in the
+    bins that sit ON a threshold (its one-sided transform stores the self-conjugate column's twin bins
+    separately, the other twins as exact copies: which pairs straddle a rank changes) - so the bar
+    is the usual one against the oracle run in EITHER orientation."""
+    from oracle import spectral_oracle as so
+    assert engine.lib.shape_supported(*shape) and not engine.lib.length_supported(shape[1])
+    base, fts = _layer_inputs(shape, 2, 300)
+    out, rep, delta = engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, want_delta=True)
+    assert out.shape == base.shape and delta.shape == base.shape
+    resid = []
+    for flip in (False, True):
+        tr = so.LayerTrace()
+        tt = (lambda x: x.T.contiguous()) if flip else (lambda x: x)
+        ref = so.merge_layer([tt(f) for f in fts], [tt(base)] * 2, so.ALPHAS[:2], tt(base), trace=tr)
+        pc.check_layer_steps(rep, tr, out.numel())
+        resid.append((pc.spectral_residual(tt(delta), tr.merged_delta)[1], so.rel_err(tt(out).float(), ref.float())))
+    assert min(r[0] for r in resid) < 2e-5 and max(r[0] for r in resid) < 2e-2
+    assert min(r[1] for r in resid) < 8.0 / (out.numel() ** 0.5)
+    # K = 3 through the same path
+    base, fts = _layer_inputs(shape, 3, 301)
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, want_delta=True)
+    assert rep.branches == tr.branches and so.rel_err(out.float(), ref.float()) < 1e-2
+
+
+def test_shapes_no_orientation_can_take_are_refused(engine):
+    assert not engine.lib.shape_supported(34, 38)            # 17 * 2 x 19 * 2: neither length has a plan
+    assert not engine.lib.shape_supported(17, 64)            # odd rough column length
+    base, fts = _layer_inputs((34, 38), 2, 5)
+    with pytest.raises(NotImplementedError):
+        engine.merge_layer(fts, [base] * 2, [1.0, 1.0], base)
+    base, fts = _layer_inputs((2, 34, 8), 2, 5)              # rank > 2: the slices' lengths need plans
+    with pytest.raises(NotImplementedError):
+        engine.merge_layer(fts, [base] * 2, [1.0, 1.0], base)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 128), (172, 128), (64, 86)], ids=lambda s: "x".join(map(str, s)))
+def test_arith_and_linear_branches_on_sliced_geometries(engine, shape):
+    """The Arithmetic-FFT branch (ratio < 0.1) and the linear blend (ratio < b) run on the layer's own
+    geometry: every slice of a rank > 2 tensor (the arithmetic branch used to transform the first slice
+    only), the row blocks of a split column length, the transposed operands of a rough row length."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(9)
+    base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+    fts = [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16) for s_ in (0.004, 0.0002)]
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * 2, [1.0, 1.0], base, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * 2, [1.0, 1.0], base, want_delta=True)
+    assert tr.branches == ["arith"] and rep.branches == ["arith"]
+    assert so.rel_err(delta, tr.merged_delta) < 2e-6 and so.rel_err(out.float(), ref.float()) < 1e-4       # a bf16 rounding flip or two
+    fts = [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16) for s_ in (0.004, 0.0015)]
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * 2, [1.0, 1.0], base, ratio_b=0.6, trace=tr)
+    out, rep, delta = engine.merge_layer(fts, [base] * 2, [1.0, 1.0], base, b=0.6, want_delta=True)
+    assert tr.branches == ["linear"] and rep.branches == ["linear"]
+    assert so.rel_err(delta, tr.merged_delta) < 2e-6 and so.rel_err(out.float(), ref.float()) < 1e-3

@@ -552,3 +552,56 @@ def test_rank3_tensor_on_device(engine, k):
 @pytest.mark.parametrize("case", gi.CORR_CASES, ids=lambda c: c["id"])
 def test_correlate_pairs_on_device(engine, golden, case):
     emul_tier.test_correlate_pairs(engine, golden, case)
+
+
+# ---- column / row lengths without a work-group plan (k_dftp, transposed merge) ------------------------
+@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("k", [2, 3])
+def test_split_column_length_on_device(engine, shape, k):
+    emul_tier.test_column_length_without_a_plan_is_split_into_row_blocks(engine, shape, k)
+
+
+@pytest.mark.parametrize("p", [2, 4, 8])
+@pytest.mark.parametrize("k", [2, 3])
+def test_forced_split_on_device(engine, p, k):
+    emul_tier.test_forced_split_agrees_with_the_plain_column_pass(engine, p, k)
+
+
+@pytest.mark.parametrize("shape", [(64, 34), (96, 76), (1, 68), (128, 2 * 43)], ids=lambda s: "x".join(map(str, s)))
+def test_transposed_merge_on_device(engine, shape):
+    emul_tier.test_row_length_without_a_plan_is_merged_transposed(engine, shape)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 128), (172, 128), (64, 86)], ids=lambda s: "x".join(map(str, s)))
+def test_arith_and_linear_branches_on_sliced_geometries_on_device(engine, shape):
+    emul_tier.test_arith_and_linear_branches_on_sliced_geometries(engine, shape)
+
+
+def test_unsupported_shapes_are_refused_on_device(engine):
+    emul_tier.test_shapes_no_orientation_can_take_are_refused(engine)
+
+
+@pytest.mark.parametrize("shape", [(11008, 4096), (4096, 11008), (18944, 3584)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_llama2_and_qwen2_mlp_shapes_k2_vs_exact_norm_oracle(engine, shape):
+    """The MLP tensors of Llama-2-7B (11008 = 43 * 256) and Qwen2-7B (18944 = 37 * 512) at FULL size,
+    the 4096 x 11008 down-projection through the transposed path: K = 2 against the exact-norm oracle
+    (run in both orientations for the transposed shape, see the emulator tier's test)."""
+    _oracle_threads()
+    rows, cols = shape
+    base, fts = so.synthetic_layer(rows, cols, 2, seed=77 + rows + cols)
+    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
+    out, delta = out.cpu(), delta.cpu()
+    flips = (False, True) if not engine.lib.length_supported(cols) else (False,)
+    best = None
+    for flip in flips:
+        tt = (lambda x: x.T.contiguous()) if flip else (lambda x: x)
+        trx = so.LayerTrace()
+        with so.exact_norms():
+            refx = so.merge_layer([tt(f) for f in fts], [tt(base)] * 2, so.ALPHAS[:2], tt(base), trace=trx)
+        pc.check_layer_steps(rep, trx, out.numel())
+        d_total, d_resid = pc.spectral_residual(tt(delta), trx.merged_delta, drop=64)
+        o_err = so.rel_err(tt(out).float(), refx.float())
+        mism = (tt(out).view(torch.int16) != refx.view(torch.int16)).float().mean().item()
+        assert d_total < 1e-3 and o_err < 1e-3 and mism < 0.08
+        best = d_resid if best is None else min(best, d_resid)
+    assert best < 5e-6, f"beyond the tie bins: {best:.2e}"
