@@ -701,6 +701,18 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
 // =====================================================================
 // F2: forward column pass (one half-spectrum bin column of A and of B)
 // =====================================================================
+// One launch over the slices of a rank > 2 tensor or the row blocks of a split column length: the
+// grid is `wgs` work-groups per slice (0: a single slice); the slices' T1 / G and planes lie
+// t1_stride (float4, or float2 for G) and plane_stride (floats) apart.
+struct SliceGrid { int wgs = 0; size_t t1_stride = 0, plane_stride = 0; };
+template <class Ex> SM_HD int slice_of(Ex& ex, const SliceGrid& sl, int& bid) {
+    bid = ex.bid();
+    if (sl.wgs <= 0) return 0;
+    const int s = bid / sl.wgs;
+    bid -= s * sl.wgs;
+    return s;
+}
+
 struct F2Params {
     FftPlanDev plan;       // N = R
     const cf4* t1;
@@ -717,6 +729,7 @@ struct F2Params {
     int Cb_real;           // bins per slab that exist (C/2 + 1)
     int Rfull;             // 4 * R: a bin column of the planes
     size_t slab_elems;     // float4 per k1 slab of T1 (slab-major: the row stride stays one real pitch)
+    SliceGrid sl;          // several slices (rank > 2 tensor / row blocks of a split column length) in one launch
 };
 // virtual column v of a folded column pass -> plane offset of its first element, real bin (or -1)
 SM_HD int fold_bin(int v, int slab, int Cb_real, int R2, int Rfull, size_t& off) {
@@ -760,7 +773,10 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
     const int LF = plan_lds<P>(pl);
     const int ng = P::is_static ? f2_nsig_for(T) : p.nsig;              // compile-time for static plans
     const int ilv = FOLD ? FOLD_ILV : (P::is_static ? t1_interleave_rows(R) : p.ilv);
-    const int bid = ex.bid();
+    int bid;
+    const int slice = slice_of(ex, p.sl, bid);
+    const cf4* const t1 = p.t1 + slice * p.sl.t1_stride;
+    const size_t pl_off = slice * p.sl.plane_stride;
     // 8/BINS work-groups share a 128-byte line of T1 (16 bytes per bin)
     // (one signal per work-group, T = 1024: the 16 work-groups of a line - 8 bins x 2 signals)
     const int lbid = (ng == 2) ? xcd_remap(bid, 8 / BINS) : xcd_remap(bid, 16);
@@ -787,9 +803,9 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                     if constexpr (FOLD) {
                         // slab-major T1: virtual column k2 = (k1, bin) lives in slab k1, row pitch = slab
                         if (n < R && k2 < p.Cb)
-                            v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)m * p.slab + (k2 % p.slab)) * ILV + q % ILV];
+                            v = t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)m * p.slab + (k2 % p.slab)) * ILV + q % ILV];
                     } else {
-                        if (n < R && k2 < p.Cb) v = p.t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
+                        if (n < R && k2 < p.Cb) v = t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
                     }
                     s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
                 }
@@ -802,7 +818,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                 const int n = tid + q * T;
                 float re = 0.f, im = 0.f;
                 if (n < R) {
-                    const cf2* src = (const cf2*)(p.t1 + ((size_t)(n / ilv) * p.pitch4 + kbase) * ilv + n % ilv) + slot0;
+                    const cf2* src = (const cf2*)(t1 + ((size_t)(n / ilv) * p.pitch4 + kbase) * ilv + n % ilv) + slot0;
                     re = src->x; im = src->y;
                 }
                 s.xr[q] = re; s.xi[q] = im;
@@ -862,8 +878,8 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         int kreal = k2;
         if constexpr (FOLD) { kreal = fold_bin(k2, p.slab, p.Cb_real, R, p.Rfull, poff); if (kreal < 0) return; }
         const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
-        float* dre = (role_a ? p.reA : p.reB) + poff;
-        float* dim = p.imA + poff;
+        float* dre = (role_a ? p.reA : p.reB) + pl_off + poff;
+        float* dim = p.imA + pl_off + poff;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);
@@ -944,6 +960,7 @@ struct F2SParams {
     size_t slab_elems;
     double* im_partials;        // role a only, or null: [grid] sum w (Im a)^2 of what this work-group stored
                                 // (the Parseval norm of the pair's result when it stays spectral)
+    SliceGrid sl;
 };
 template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
@@ -964,7 +981,11 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     const int T = plan_T<P>(pl), R = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
     constexpr int XG = G >= 8 ? 1 : 8 / G;                 // work-groups that share a 128-byte line of T1
-    const int lbid = xcd_remap(ex.bid(), XG);
+    int bid_in_slice;
+    const int slice = slice_of(ex, p.sl, bid_in_slice);
+    const cf4* const t1 = p.t1 + slice * p.sl.t1_stride;
+    const size_t pl_off = slice * p.sl.plane_stride;
+    const int lbid = xcd_remap(bid_in_slice, XG);
     const int kbase = lbid * G;
     if (kbase >= p.Cb) {                      // padding work-group: its partial must still read zero
         if (p.im_partials) ex.each(st, [&](int tid, FftState&) { if (tid == 0) p.im_partials[ex.bid()] = 0.0; });
@@ -983,9 +1004,9 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
             cf4 v = {0.f, 0.f, 0.f, 0.f};
             if constexpr (FOLD) {
                 if (m < half && k2 < p.Cb)
-                    v = p.t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)(m / F2S_ILV) * p.slab + (k2 % p.slab)) * F2S_ILV + m % F2S_ILV];
+                    v = t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)(m / F2S_ILV) * p.slab + (k2 % p.slab)) * F2S_ILV + m % F2S_ILV];
             } else {
-                if (m < half && k2 < p.Cb) v = p.t1[((size_t)(m / F2S_ILV) * p.pitch4 + k2) * F2S_ILV + m % F2S_ILV];
+                if (m < half && k2 < p.Cb) v = t1[((size_t)(m / F2S_ILV) * p.pitch4 + k2) * F2S_ILV + m % F2S_ILV];
             }
             s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
         }
@@ -1029,8 +1050,8 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         int kreal = k2;
         if constexpr (FOLD) { kreal = fold_bin(k2, p.slab, p.Cb_real, R, p.Rfull, poff); if (kreal < 0) return; }
         const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
-        float* dre = p.re + poff;
-        float* dim = p.im + poff;
+        float* dre = p.re + pl_off + poff;
+        float* dim = p.im + pl_off + poff;
         float imsq = 0.f;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
@@ -1131,6 +1152,7 @@ struct I1Params {
     int s;                 // bin columns per work-group
     cf2* G;                // [R][pitchG]
     int pitchG;
+    SliceGrid sl;          // (t1_stride counts float2 of G here)
 };
 
 // FOLD: the planes hold each bin column in the folded order [k1][k2] (k = k1 + 4 k2, see k_f1q):
@@ -1148,7 +1170,11 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
     const FftPlanDev& pl = p.plan;
     const int T = plan_T<P>(pl), R = plan_N<P>(pl);
     const int LF = plan_lds<P>(pl);
-    const int bid = xcd_remap(ex.bid(), 16 / S);      // 16 bins of 8 B share a 128-B line
+    int bid_in_slice;
+    const int slice = slice_of(ex, p.sl, bid_in_slice);
+    const size_t pl_off = slice * p.sl.plane_stride;
+    cf2* const Gs = p.G + slice * p.sl.t1_stride;
+    const int bid = xcd_remap(bid_in_slice, 16 / S);      // 16 bins of 8 B share a 128-B line
     if (bid * S >= p.Cb) return;
     const float thr = p.cull_thr ? *p.cull_thr : p.cull_val;
 
@@ -1156,8 +1182,8 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         const int g = tid / T, t = tid % T;
         const int k2 = bid * S + g;
         const bool valid = k2 < p.Cb;
-        const float* sre = p.reR + (size_t)k2 * R;
-        const float* sim = p.imA + (size_t)k2 * R;
+        const float* sre = p.reR + pl_off + (size_t)k2 * R;
+        const float* sim = p.imA + pl_off + (size_t)k2 * R;
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);            // FOLD: four consecutive elements of one slab
@@ -1232,7 +1258,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         for (int j = 0; j < EMAX / (2 * S); ++j) {
             const int m = tid + j * S * T;
             if (2 * m < R) {
-                cf4* dst = (cf4*)p.G + (size_t)m * p.pitchG + (size_t)bid * S;
+                cf4* dst = (cf4*)Gs + (size_t)m * p.pitchG + (size_t)bid * S;
                 const bool odd = 2 * m + 1 < R;
 #pragma unroll
                 for (int g = 0; g < S; ++g) {
@@ -3141,6 +3167,7 @@ SM_HD void k_cull(Ex& ex, const CullParams& p) {
 // =====================================================================
 constexpr int DFTP_MAX_P = 256;
 constexpr int DFTP_COLS = 16;          // bin columns per work-group: 16 x 16 B = 256 contiguous bytes
+constexpr int DFTP_KB = 4;             // outputs a thread accumulates together
 struct DftpParams {
     cf4* buf;              // T1 (forward) or G (inverse): p slices
     const cf2* tw;         // tw[j] = exp(-2 pi i j / (p M)), j < p M
@@ -3185,27 +3212,149 @@ SM_HD void k_dftp(Ex& ex, const DftpParams& p) {
         }
     });
     ex.sync();
+    // a thread owns one column and the outputs k = kl + j * (nt / 16): DFTP_KB of them share every tile
+    // value it reads, and the two complex halves of a cf4 ride the packed-f32 ALU ops side by side
     ex.each(st, [&](int tid, EmptyState&) {
-        for (int idx = tid; idx < p.p * DFTP_COLS; idx += nt) {
-            const int k = idx / DFTP_COLS, cl = idx % DFTP_COLS, c = c0 + cl;
-            if (c >= p.ncols) continue;
-            float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
-            int wi = 0;
-            for (int s = 0; s < p.p; ++s) {
-                const cf4 v = tile[s * DFTP_COLS + cl];
-                const cf2 w = wp[wi];
-                ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
-                br += v.z * w.x - v.w * w.y; bi += v.z * w.y + v.w * w.x;
-                wi += k; if (wi >= p.p) wi -= p.p;
+        const int cl = tid % DFTP_COLS, kl = tid / DFTP_COLS, kstep = nt / DFTP_COLS;
+        const int c = c0 + cl;
+        if (c >= p.ncols) return;
+        for (int kb0 = kl; kb0 < p.p; kb0 += kstep * DFTP_KB) {
+            vf2 accr[DFTP_KB], acci[DFTP_KB];
+            int kk[DFTP_KB], wi[DFTP_KB];
+#pragma unroll
+            for (int j = 0; j < DFTP_KB; ++j) {
+                const int k = kb0 + j * kstep;
+                kk[j] = k < p.p ? k : 0;                 // (a lane past the end computes output 0 again and drops it)
+                wi[j] = 0; accr[j] = mk2(0.f, 0.f); acci[j] = mk2(0.f, 0.f);
             }
-            cf2 a = {ar, ai}, b = {br, bi};
-            if (!p.inverse) {                      // slice index k is k2
-                a = cmul(a, p.tw[(size_t)n1a * k]); b = cmul(b, p.tw[(size_t)n1b * k]);
+            for (int sidx = 0; sidx < p.p; ++sidx) {
+                const cf4 v = tile[sidx * DFTP_COLS + cl];
+                const vf2 vr = mk2(v.x, v.z), vi = mk2(v.y, v.w);
+#pragma unroll
+                for (int j = 0; j < DFTP_KB; ++j) {
+                    const cf2 w = wp[wi[j]];
+                    accr[j] += vr * w.x - vi * w.y;
+                    acci[j] += vr * w.y + vi * w.x;
+                    wi[j] += kk[j]; if (wi[j] >= p.p) wi[j] -= p.p;
+                }
             }
-            cf4 o = {a.x, a.y, b.x, b.y};
-            p.buf[(size_t)k * p.slice_stride + row_off + (size_t)c * p.ilv] = o;
+#pragma unroll
+            for (int j = 0; j < DFTP_KB; ++j) {
+                const int k = kb0 + j * kstep;
+                if (k >= p.p) continue;
+                cf2 a = {accr[j].x, acci[j].x}, b = {accr[j].y, acci[j].y};
+                if (!p.inverse) {                  // slice index k is k2
+                    a = cmul(a, p.tw[(size_t)n1a * k]); b = cmul(b, p.tw[(size_t)n1b * k]);
+                }
+                cf4 o = {a.x, a.y, b.x, b.y};
+                p.buf[(size_t)k * p.slice_stride + row_off + (size_t)c * p.ilv] = o;
+            }
         }
     });
+}
+
+// The same transform for p <= DFTP_PAIR_MAX_P with half the multiplies and no index arithmetic in the inner
+// loop (the generic kernel spends more instructions on (s k) mod p than on the sums).  Outputs k and
+// p - k use conjugate twiddles (c, -+s): with A = sum vr c, B = sum vi s, C = sum vr s, D = sum vi c
+//     X[k] = (A - B, C + D),   X[p - k] = (A + B, D - C)
+// so a "pair unit" h = 0 .. p/2 costs four (packed) FMAs per input for two outputs.  The matrix
+// Wh[s][h] = W_p^(s h) sits in LDS, filled once per work-group, which then walks DFTP_UNITS row units.
+constexpr int DFTP_PAIR_MAX_P = 126;
+constexpr int DFTP_UNITS = 4;
+SM_HD size_t dftp_pairs_lds_bytes(int p) {
+    const int H = p / 2 + 1;
+    return (size_t)p * DFTP_COLS * sizeof(cf4) + (size_t)p * H * sizeof(cf2);
+}
+template <int NP, class Ex, class St>
+SM_HD void dftp_pairs_compute(Ex& ex, St& st, const DftpParams& p, const cf4* tile, const cf2* wh, int H, int c0,
+                              size_t row_off, int n1a, int n1b) {
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const int cl = tid % DFTP_COLS, hl = tid / DFTP_COLS, hstep = nt / DFTP_COLS;
+        const int c = c0 + cl;
+        if (c >= p.ncols) return;
+        vf2 A[NP], B[NP], C[NP], D[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { A[j] = mk2(0.f, 0.f); B[j] = A[j]; C[j] = A[j]; D[j] = A[j]; }
+        const cf4* tp = tile + cl;
+        const cf2* wq = wh + hl;                   // unit h = hl + j * hstep (reads past H land in the padding row)
+        for (int sidx = 0; sidx < p.p; ++sidx) {
+            const cf4 v = *tp;
+            const vf2 vr = mk2(v.x, v.z), vi = mk2(v.y, v.w);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const cf2 w = wq[j * hstep];
+                A[j] += vr * w.x; B[j] += vi * w.y; C[j] += vr * w.y; D[j] += vi * w.x;
+            }
+            tp += DFTP_COLS; wq += H;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int h = hl + j * hstep;
+            if (h >= H) continue;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int k = side == 0 ? h : p.p - h;
+                if (side == 1 && (h == 0 || 2 * h == p.p)) continue;          // its own partner
+                const vf2 re = side == 0 ? A[j] - B[j] : A[j] + B[j];
+                const vf2 im = side == 0 ? C[j] + D[j] : D[j] - C[j];
+                cf2 a = {re.x, im.x}, b = {re.y, im.y};
+                if (!p.inverse) { a = cmul(a, p.tw[(size_t)n1a * k]); b = cmul(b, p.tw[(size_t)n1b * k]); }
+                cf4 o = {a.x, a.y, b.x, b.y};
+                p.buf[(size_t)k * p.slice_stride + row_off + (size_t)c * p.ilv] = o;
+            }
+        }
+    });
+}
+template <class Ex>
+SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const int H = p.p / 2 + 1;
+    cf4* tile = (cf4*)(ex.lds() + LDS_SCRATCH_FLOATS);             // [p][DFTP_COLS]
+    cf2* wh = (cf2*)(tile + (size_t)p.p * DFTP_COLS);               // [p][H] (+ slack: the launch adds a row)
+    const int ntiles = (p.ncols + DFTP_COLS - 1) / DFTP_COLS;
+    const int ug = ex.bid() / ntiles, c0 = (ex.bid() % ntiles) * DFTP_COLS;
+    const float sgn_im = p.inverse ? -1.f : 1.f;
+    ex.each(st, [&](int tid, EmptyState&) {
+        for (int idx = tid; idx < p.p * H; idx += nt) {
+            const int sidx = idx / H, h = idx % H;
+            cf2 w = p.tw[(size_t)((sidx * h) % p.p) * p.M];
+            w.y *= sgn_im;
+            wh[idx] = w;
+        }
+        for (int idx = p.p * H + tid; idx < (p.p + 1) * H + 4 * (nt / DFTP_COLS); idx += nt) { cf2 z = {0.f, 0.f}; wh[idx] = z; }
+    });
+    for (int uu = 0; uu < DFTP_UNITS; ++uu) {
+        const int u = ug * DFTP_UNITS + uu;
+        if (u >= p.units) break;
+        const int n1a = p.rowpair ? 2 * u : u, n1b = p.rowpair ? 2 * u + 1 : u;
+        const size_t row_off = ((size_t)(u / p.ilv) * p.pitch) * p.ilv + u % p.ilv;
+        ex.sync();                                   // the previous unit's tile has been consumed (and wh is filled)
+        ex.each(st, [&](int tid, EmptyState&) {
+            for (int idx = tid; idx < p.p * DFTP_COLS; idx += nt) {
+                const int sidx = idx / DFTP_COLS, c = c0 + idx % DFTP_COLS;
+                cf4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < p.ncols) {
+                    v = p.buf[(size_t)sidx * p.slice_stride + row_off + (size_t)c * p.ilv];
+                    if (p.inverse) {
+                        cf2 wa = p.tw[(size_t)n1a * sidx], wb = p.tw[(size_t)n1b * sidx];
+                        wa.y = -wa.y; wb.y = -wb.y;
+                        const cf2 a = cmul({v.x, v.y}, wa), b = cmul({v.z, v.w}, wb);
+                        v = {a.x, a.y, b.x, b.y};
+                    }
+                }
+                tile[idx] = v;
+            }
+        });
+        ex.sync();
+        const int np = (H + nt / DFTP_COLS - 1) / (nt / DFTP_COLS);
+        if (np <= 1) dftp_pairs_compute<1>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
+        else if (np == 2) dftp_pairs_compute<2>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
+        else if (np == 3) dftp_pairs_compute<3>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
+        else dftp_pairs_compute<4>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
+    }
 }
 
 // [R][C] -> [C][R], elements of 2 or 4 bytes moved as bits (32 x 32 tiles through LDS): a tensor

@@ -155,6 +155,7 @@ SM_KERNEL_TAG(KSumsqCand, SumsqCandParams, "spec_norm_cand", k_sumsq_cand(ex, p)
 SM_KERNEL_TAG(KSumSpec, SumSpecParams, "spec_norm_sum", k_sum_spec(ex, p))
 SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex, p))
 SM_KERNEL_TAG(KDftp, DftpParams, "dft_across_slices", k_dftp(ex, p))
+SM_KERNEL_TAG(KDftpPairs, DftpParams, "dft_across_slices", k_dftp_pairs(ex, p))
 SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
 
 // ---- FFT planner ---------------------------------------------------------------
@@ -249,6 +250,7 @@ class Pipeline {
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
+    bool dftp_pairs_enabled = true;   // test hook: 0 = the generic k_dftp for every p
     int debug_force_split = 0;        // test hook: split a column length into this many row blocks even if it has a plan
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
@@ -518,6 +520,12 @@ class Pipeline {
         q.buf = (cf4*)buf; q.p = g.rough; q.M = g.R; q.units = rowpair ? g.R / 2 : g.R; q.rowpair = rowpair ? 1 : 0;
         q.ilv = ilv; q.pitch = pitch; q.ncols = g.C / 2 + 1; q.slice_stride = slice_stride; q.inverse = inverse ? 1 : 0;
         const int ntiles = (q.ncols + DFTP_COLS - 1) / DFTP_COLS;
+        if (q.p <= DFTP_PAIR_MAX_P && dftp_pairs_enabled) {
+            // (+ one zero row of Wh and 4 * 16 entries: the unrolled units past H read there)
+            const size_t ldsp = LDS_SCRATCH_FLOATS * 4 + dftp_pairs_lds_bytes(q.p) + ((size_t)(q.p / 2 + 1) + 64) * sizeof(cf2);
+            be.template launch<KDftpPairs>((q.units + DFTP_UNITS - 1) / DFTP_UNITS * ntiles, 256, ldsp, q, stream);
+            return SMHIP_OK;
+        }
         const size_t lds = LDS_SCRATCH_FLOATS * 4 + (size_t)q.p * DFTP_COLS * sizeof(cf4) + (size_t)q.p * sizeof(cf2);
         be.template launch<KDftp>(q.units * ntiles, 256, lds, q, stream);
         return SMHIP_OK;
@@ -645,14 +653,9 @@ class Pipeline {
         if (im_parts) *im_parts = want_im ? grid * g.batch : -1;
         p.im_partials = want_im ? d_part_im() : nullptr;
         if (g.fold == 4) { launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p); return SMHIP_OK; }
-        const cf4* const t1base = p.t1;
-        const size_t pslice = (size_t)(g.C / 2 + 1) * g.R;              // plane floats per slice
-        for (int bi = 0; bi < g.batch; ++bi) {
-            p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
-            p.re = plane(g, role_a ? P_REA : P_REB) + bi * pslice; p.im = plane(g, P_IMA) + bi * pslice;
-            p.im_partials = want_im ? d_part_im() + (size_t)bi * grid : nullptr;
-            launch_fft<KF2S>(p.plan, grid, G * p.plan.T, lds, p);
-        }
+        // every slice in one launch (im_partials is indexed by the global work-group id)
+        if (g.batch > 1) { p.sl.wgs = grid; p.sl.t1_stride = g.t1_slice / 2; p.sl.plane_stride = (size_t)(g.C / 2 + 1) * g.R; }
+        launch_fft<KF2S>(p.plan, grid * g.batch, G * p.plan.T, lds, p);
         return SMHIP_OK;
     }
     // sum over the full spectrum of |R_culled|^2 of the planes (re, im) -> (sum_re, sum_im), one sync
@@ -756,12 +759,8 @@ class Pipeline {
         const int ngroups = p.nsig == 2 ? 2 * bins : 1;
         const int grid = p.nsig == 2 ? (int)round_up((size_t)(p.Cb + bins - 1) / bins, 64) : (int)round_up((size_t)p.Cb * 2, 128);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)ngroups * p.plan.lds_floats + HIST1_BINS) * 4;
-        const size_t pslice = (size_t)(g.C / 2 + 1) * g.R;              // plane floats per slice
-        for (int bi = 0; bi < g.batch; ++bi) {
-            p.t1 = (const cf4*)t1_.p + (size_t)bi * g.t1_slice;
-            p.reA = plane(g, P_REA) + bi * pslice; p.imA = plane(g, P_IMA) + bi * pslice; p.reB = plane(g, P_REB) + bi * pslice;
-            launch_fft<KF2>(p.plan, grid, ngroups * p.plan.T, lds, p);
-        }
+        if (g.batch > 1) { p.sl.wgs = grid; p.sl.t1_stride = g.t1_slice; p.sl.plane_stride = (size_t)(g.C / 2 + 1) * g.R; }
+        launch_fft<KF2>(p.plan, grid * g.batch, ngroups * p.plan.T, lds, p);     // every slice in one launch
         return SMHIP_OK;
     }
 
@@ -905,6 +904,15 @@ class Pipeline {
         for (int bi = 0; bi < g.batch; ++bi) {
             if (g.rough > 1) { a.G = (cf2*)t1_.p + (size_t)bi * g.t1_slice; b.G = a.G; }
             a.reR = reR + bi * pslice; a.imA = imA + bi * pslice;
+            if (phases == 2 && phase == 0 && g.R > 1) {      // the column pass of every row block in one launch
+                if (bi > 0) break;
+                a.G = (cf2*)t1_.p;
+                a.sl.wgs = grid1; a.sl.t1_stride = g.t1_slice; a.sl.plane_stride = pslice;
+                const int gridj = grid1 * g.batch;
+                if (a.s >= 2) launch_fft<KI1x2>(a.plan, gridj, a.s * a.plan.T, lds1, a);
+                else launch_fft<KI1x1>(a.plan, gridj, a.plan.T, lds1, a);
+                continue;
+            }
             if (phases == 2 && phase == 1) {
                 // rows only
             } else

@@ -582,3 +582,22 @@ def test_arith_and_linear_branches_on_sliced_geometries(engine, shape):
     out, rep, delta = engine.merge_layer(fts, [base] * 2, [1.0, 1.0], base, b=0.6, want_delta=True)
     assert tr.branches == ["linear"] and rep.branches == ["linear"]
     assert so.rel_err(delta, tr.merged_delta) < 2e-6 and so.rel_err(out.float(), ref.float()) < 1e-3
+
+
+def test_generic_dft_kernel_agrees_with_the_paired_one(engine):
+    """k_dftp_pairs (p <= 126) and the generic k_dftp (any p <= 256) on the same tensor, both directions
+    and both T1 layouts (K = 2: two-signal row pass; K = 3: row pairs)."""
+    from oracle import spectral_oracle as so
+    for k, shape in ((2, (172, 128)), (3, (136, 96))):
+        base, fts = _layer_inputs(shape, k, 55)
+        fast = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+        engine.ctx.debug_option("dftp_pairs", 0)
+        try:
+            slow = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+        finally:
+            engine.ctx.debug_option("dftp_pairs", 1)
+        assert fast[1].branches == slow[1].branches
+        if k == 2:
+            assert pc.spectral_residual(fast[2], slow[2])[1] < 2e-6
+        else:
+            assert so.rel_err(fast[2], slow[2]) < 3e-2

@@ -605,3 +605,7 @@ def test_llama2_and_qwen2_mlp_shapes_k2_vs_exact_norm_oracle(engine, shape):
         assert d_total < 1e-3 and o_err < 1e-3 and mism < 0.08
         best = d_resid if best is None else min(best, d_resid)
     assert best < 5e-6, f"beyond the tie bins: {best:.2e}"
+
+
+def test_generic_dft_kernel_on_device(engine):
+    emul_tier.test_generic_dft_kernel_agrees_with_the_paired_one(engine)
