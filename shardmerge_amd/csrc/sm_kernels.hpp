@@ -928,14 +928,20 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
 #ifndef SM_COL_THREADS
 #define SM_COL_THREADS 512
 #endif
-constexpr int f2_bins_for(int T) { return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1; }
+// (the 256-point row blocks of a split column length are so short that a work-group's fixed
+//  costs - its histogram flush above all: the same ~150 hot addresses from every work-group - outweigh
+//  its payload: 8 bins there, whole 128-byte lines of T1, half the work-groups)
+constexpr int f2_bins_for(int T, int N = 1 << 30) {
+    if (T == 64 && N <= 256) return 8;        // (measured: 512-point blocks lose 20 % with 8)
+    return (SM_COL_THREADS / (2 * T)) > 1 ? (SM_COL_THREADS / (2 * T) > 8 ? 8 : SM_COL_THREADS / (2 * T)) : 1;
+}
 // the inverse column pass measured fastest with two bins per work-group at every length
 #ifndef SM_I1_THREADS
 constexpr int i1_bins_for(int T) { return 2; }     // the host launches KI1x1 instead when 2T is too large
 #else
 constexpr int i1_bins_for(int T) { return (SM_I1_THREADS / T) > 2 ? ((SM_I1_THREADS / T) > 16 ? 16 : (SM_I1_THREADS / T)) : 2; }
 #endif
-template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T); else return 1; }
+template <class P> constexpr int f2_bins() { if constexpr (P::is_static) return f2_bins_for(P::T, P::N); else return 1; }
 template <class P> constexpr int i1_bins() { if constexpr (P::is_static) return i1_bins_for(P::T); else return 2; }
 
 // ---------------------------------------------------------------------------------
@@ -963,7 +969,7 @@ struct F2SParams {
     SliceGrid sl;
 };
 template <class P> constexpr int f2s_groups() {
-    if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T) : 1; else return 1;
+    if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T, P::N) : 1; else return 1;
 }
 
 #ifndef SM_F2S_ILV

@@ -97,7 +97,7 @@ SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(
     X(SPlan<13824, 512, false, 4, 32, 16, 3, 3, 3>) \
     X(SPlan<27648, 1024, false, 4, 32, 32, 3, 3, 3>) \
     X(SPlan<2304, 128, false, 4, 16, 16, 3, 3>) \
-    X(SPlan<256, 64, false, 4, 16, 16>)            \
+    X(SPlan<256, 64, false, 4, 8, 8, 4>)            \
     X(SPlan<512, 64, false, 4, 32, 16>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
@@ -453,7 +453,7 @@ class Pipeline {
 #undef SM_IS_PLAN
         return found;
     }
-    static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T) : 1; }
+    static int f2_bins_host(const FftPlanDev& pl) { return is_static_plan(pl) ? f2_bins_for(pl.T, pl.N) : 1; }
     static int i1_bins_host(const FftPlanDev& pl) {
         // two bins per work-group up to 512 threads; the 512-thread plans run one bin per
         // work-group (two independent groups per CU, as in the forward column pass)
@@ -645,7 +645,7 @@ class Pipeline {
         p.re = plane(g, role_a ? P_REA : P_REB); p.im = plane(g, P_IMA);
         p.hist = hist ? d_hist() : nullptr;
         const bool st = is_static_plan(p.plan);
-        const int G = st ? (f2_nsig_for(p.plan.T) == 2 ? 2 * f2_bins_for(p.plan.T) : 1) : 1;
+        const int G = st ? (f2_nsig_for(p.plan.T) == 2 ? 2 * f2_bins_for(p.plan.T, p.plan.N) : 1) : 1;
         const int xg = G >= 8 ? 1 : 8 / G;
         const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
