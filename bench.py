@@ -89,7 +89,9 @@ KERNEL_ALG_BYTES = {
     "i2_rows_inv": 8.0,      # read 4n + base 2n + write bf16 2n   (or: read 4n + write fp32 4n)
     "blend": 6.0,
     "slerp_reduce": 4.0,
-    "select_lvl2": 3.0,      # 4n on (Re a, Re b) + 2n on Re R: two launches per pair, 3n on average
+    "select_lvl2": 4.0,      # the cutoff's level-2 pass over (Re a, Re b)
+    "select_lvl2_cull": 0.0, # the cull's level-2 pass over Re R: normally done inside the blend's sweep (speculation on the
+                             # threshold's level-1 bin), this launch then returns at once; 2n when it has to run
     "select_hist": 3.0,
     "combine": 6.0,
 }
@@ -112,10 +114,10 @@ def kernel_alg_bytes_per_elem(name: str, k: int) -> float:
             "i1_cols_inv": 8.0, "i2_rows_inv": 8.0,        # the final inverse only
             "spec_norm": inter * 4.0,                      # Re R + Im a (fallback: normally fused into select_lvl2 / f2s)
             "spec_rescale": inter * 4.0,                   # role b: Re in, Re out (role a: 8n)
-            "select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs,
+            "select_hist": per * 2 * pairs,
         }
     else:
-        table = {"select_lvl2": per * 2 * pairs, "select_hist": per * 2 * pairs}
+        table = {"select_hist": per * 2 * pairs}
     if k >= 2 and name in table:
         return table[name]
     return per * pairs

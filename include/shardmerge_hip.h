@@ -167,6 +167,8 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
  *      "force_split" = p splits the column length of smhip_merge_layer into p row blocks (the path of
  *      lengths without a plan, smhip_shape_supported) although it has one, 0 = off;
+ *      "spec_cull" = 0 keeps the SLERP blend and the cull's selection pass apart (no speculation on the
+ *      threshold's level-1 bin);
  *      "dftp_pairs" = 0 runs the generic p-point DFT kernel also for p <= 126;
  *      "sel_wgs_per_cu" the resident work-groups per CU its grid is sized for (0 = default 5), and
  *      "sel_flush_always" flushes its staged candidates after every round (the
@@ -175,6 +177,8 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
  *      (inverse transform to fp32, forward again) as round 1 of this library did, instead of
  *      keeping it in the spectral domain (default 1). ----------------------------------- */
 int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
+/* test hook, read side: "spec_hit" = 1 if the last speculative blend's guess was confirmed, 0 if it was voided */
+int smhip_debug_query(smhip_ctx* ctx, const char* key, long* value);
 
 /* ---- profiling: per-kernel device time measured with HIP events on the
  *      caller's stream (bench.py's roofline leg) ---------------------------- */

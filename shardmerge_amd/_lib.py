@@ -100,6 +100,7 @@ class SmhipLibrary:
         d.smhip_addition_merge.argtypes = [P, I, C.POINTER(C.c_void_p), P, I, C.c_size_t, I, P, P]
         d.smhip_correlate_pairs.argtypes = [P, I, C.POINTER(C.c_void_p), I, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), P]
         d.smhip_debug_option.argtypes = [P, C.c_char_p, C.c_long]
+        d.smhip_debug_query.argtypes = [P, C.c_char_p, C.POINTER(C.c_long)]
         d.smhip_profile_enable.argtypes = [P, I]
         d.smhip_profile_reset.argtypes = [P]
         d.smhip_profile_count.argtypes = [P]
@@ -148,6 +149,11 @@ class Context:
 
     def debug_option(self, key: str, value: int):
         self.check(self.lib.dll.smhip_debug_option(self.h, key.encode(), int(value)))
+
+    def debug_query(self, key: str) -> int:
+        out = C.c_long(0)
+        self.check(self.lib.dll.smhip_debug_query(self.h, key.encode(), C.byref(out)))
+        return int(out.value)
 
     def profile(self, on: bool):
         self.check(self.lib.dll.smhip_profile_enable(self.h, 1 if on else 0))

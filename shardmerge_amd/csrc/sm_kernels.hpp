@@ -1653,6 +1653,17 @@ struct CandLists {
     uint32_t cap_keys, cap_pairs;
     uint32_t* counters;    // [0] n_keys, [1] n_pairs, [2] overflow
 };
+// blend constants (device memory), written by k_slerp_consts
+struct BlendConsts {
+    float thr;        // cutoff threshold (0 when cutoff_pct == 0)
+    float dot;        // clamped cosine between the slerp-class vectors
+    float cos_t, sin_t;
+    float inv_rel;    // 1 / max(||v1 - dot v0||, 1e-12)
+    float pad[3];
+    double s00, s01, s11;
+    unsigned long long n_slerp;
+};
+
 struct Select2Params {
     const float* X; const float* Y;     // Y may be null
     int R, C, Cb;
@@ -1669,9 +1680,26 @@ struct Select2Params {
     double* partials;                   // [grid][4] when fuse_reduce or sumsq
     int chunks;
     int flush_always;          // test hook: flush the staged candidates after every round
+    const uint32_t* skip;      // plain mode, optional: *skip != 0 -> nothing to do (the speculative pass below did it)
+    // BLEND mode (k_select2<true>): X = Re a, blendB = Re b; the kernel computes Re R = blend(a, b), stores it,
+    // takes its level-1 histogram - and, SPECULATING that the cull threshold's level-1 bin is *guess - 1 (what
+    // it was the last time, 0 = no guess), does this selection pass's work on it in the same sweep.
+    // k_spec_check confirms the guess from the complete histogram or voids the speculative output.
+    const float* blendB; float* blendR;
+    const BlendConsts* consts; float t_sum;
+    unsigned long long* hist1_out;
+    const uint32_t* guess;
 };
 
-template <class Ex>
+SM_HD float blend_slerp_one(const BlendConsts& c, float t_sum, float a, float b) {      // = blend_one(), BLEND_SLERP
+    if (same_sign(a, b)) {
+        if (fabsf(b) < c.thr) return a + t_sum * b;
+        return a * c.cos_t + ((b - a * c.dot) * c.inv_rel) * c.sin_t;
+    }
+    return (fabsf(a) > fabsf(b)) ? a : b;
+}
+
+template <bool BLEND = false, class Ex>
 SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
@@ -1682,22 +1710,32 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     const int nt = ex.nthreads();
     const size_t total = (size_t)p.Cb * p.R;
     const size_t nquad = (total + 3) / 4;
-    // level 1: every work-group resolves it for itself (the staging area doubles as scratch)
-    wg_resolve(ex, st, p.hist1, HIST1_BINS, p.rank, (unsigned long long*)lkeys, lctl + 4);
-    const uint32_t prefix = lctl[4];
-    if (ex.bid() == 0) {
-        ex.each(st, [&](int tid, EmptyState&) {
-            if (tid == 0) {
-                p.sel->prefix = prefix; p.sel->level = 1;
-                p.sel->rank = (unsigned long long)lctl[5] | ((unsigned long long)lctl[6] << 32);
-            }
-        });
+    uint32_t* lh1 = lkeys + STAGE_KEYS;                 // BLEND: level-1 histogram of Re R (no pair staging there)
+    uint32_t prefix;
+    BlendConsts bc;
+    if constexpr (BLEND) {
+        prefix = *p.guess - 1u;                          // 0xffffffff: no guess, nothing matches
+        bc = *p.consts;
+    } else {
+        if (p.skip && *p.skip) return;
+        // level 1: every work-group resolves it for itself (the staging area doubles as scratch)
+        wg_resolve(ex, st, p.hist1, HIST1_BINS, p.rank, (unsigned long long*)lkeys, lctl + 4);
+        prefix = lctl[4];
+        if (ex.bid() == 0) {
+            ex.each(st, [&](int tid, EmptyState&) {
+                if (tid == 0) {
+                    p.sel->prefix = prefix; p.sel->level = 1;
+                    p.sel->rank = (unsigned long long)lctl[5] | ((unsigned long long)lctl[6] << 32);
+                }
+            });
+        }
+        ex.sync();
     }
-    ex.sync();
     const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
     ex.each(st, [&](int tid, EmptyState&) {
         for (int b = tid; b < HIST_LO_BINS; b += nt) lh[b] = 0;
         if (tid < 8) lctl[tid] = 0;
+        if constexpr (BLEND) for (int b = tid; b < HIST1_BINS; b += nt) lh1[b] = 0;
     });
     ex.sync();
     // The stream is cut into rounds of ROUND steps; after each round the staged candidates go
@@ -1710,17 +1748,27 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     ex.each(st, [&](int tid, EmptyState& s) {
         double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
         const size_t start = (size_t)ex.bid() * p.chunks * nt;
-        const bool hasY = p.Y != nullptr;
+        const bool hasY = !BLEND && p.Y != nullptr;
         // up to 4 consecutive plane elements from i0 on
         // uniform_w: the 4 elements lie in one column (R % 4 == 0), one weight serves all
-        auto quad = [&](size_t i0, const float* a, const float* b, int n, bool uniform_w) {
+        auto quad = [&](size_t i0, const float* a_in, const float* b, int n, bool uniform_w) {
             float q00 = 0.f, q01 = 0.f, q11 = 0.f, qc = 0.f;
             const uint32_t w0 = weight_at(wr, i0);
+            float rr[4];
+            const float* a = a_in;
+            if constexpr (BLEND) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rr[e] = blend_slerp_one(bc, p.t_sum, a_in[e], b[e]);
+                if (n == 4 && uniform_w) { cf4 v = {rr[0], rr[1], rr[2], rr[3]}; *(cf4*)(p.blendR + i0) = v; }
+                else for (int e = 0; e < n; ++e) p.blendR[i0 + e] = rr[e];
+                a = rr;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e < n) {
                     const uint32_t w = uniform_w ? w0 : weight_at(wr, i0 + e);
                     const uint32_t ka = f2u(a[e]) & 0x7fffffffu;
+                    if constexpr (BLEND) ex.lds_atomic_add(&lh1[ka >> 20], w);
                     if ((ka >> 20) == prefix) {
                         ex.lds_atomic_add(&lh[(ka >> 10) & 1023u], w);
                         const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
@@ -1755,7 +1803,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             // branched around so that the loads issue back to back
             constexpr int U = 4;
             const cf4* X4 = (const cf4*)p.X;
-            const cf4* Y4 = (const cf4*)p.Y;
+            const cf4* Y4 = (const cf4*)(BLEND ? p.blendB : p.Y);
             for (int c0 = r0; c0 < r1; c0 += U) {
                 cf4 av[U], bv[U];
                 size_t qv[U];
@@ -1764,7 +1812,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                     qv[u] = start + (size_t)(c0 + u) * nt + tid;
                     av[u] = X4[qv[u] < nquad ? qv[u] : nquad - 1];
                 }
-                if (hasY) {
+                if (hasY || BLEND) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) bv[u] = Y4[qv[u] < nquad ? qv[u] : nquad - 1];
                 }
@@ -1784,6 +1832,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
                 const int n = load_quad(p.X, 4 * qi, total, 0, a);
                 if (hasY) load_quad(p.Y, 4 * qi, total, 0, b);
+                if constexpr (BLEND) load_quad(p.blendB, 4 * qi, total, 0, b);
                 quad(4 * qi, a, b, n, false);
             }
         }
@@ -1803,7 +1852,8 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             const uint32_t bk = nk ? ex.global_atomic_add_ret_u32(&p.cand.counters[0], nk) : 0u;
             const uint32_t bp = np ? ex.global_atomic_add_ret_u32(&p.cand.counters[1], np) : 0u;
             if (bk + nk > p.cand.cap_keys || bp + np > p.cand.cap_pairs) over = true;
-            if (over) { ex.global_atomic_or_u32(&p.cand.counters[2], 1u); ex.global_atomic_or_u32(&p.cand.counters[3], 1u); }
+            // (a speculative pass leaves the sticky word to k_spec_check: an overflow on a wrong guess is void)
+            if (over) { ex.global_atomic_or_u32(&p.cand.counters[2], 1u); if (!BLEND) ex.global_atomic_or_u32(&p.cand.counters[3], 1u); }
             lctl[0] = nk; lctl[1] = np; lctl[2] = bk; lctl[3] = bp;
         }
     });
@@ -1822,6 +1872,12 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             const uint32_t v = lh[b];
             if (v) ex.global_atomic_add(&p.hist[b], (unsigned long long)v);
         }
+        if constexpr (BLEND) {
+            for (int b = tid; b < HIST1_BINS; b += nt) {
+                const uint32_t v = lh1[b];
+                if (v) ex.global_atomic_add(&p.hist1_out[b], (unsigned long long)v);
+            }
+        }
     });
     if (p.fuse_reduce || p.sumsq) {
         ex.sync();
@@ -1829,6 +1885,47 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
             for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
         });
     }
+}
+
+// Single work-group: was the speculated level-1 bin of k_select2<true> the right one?  Resolves level 1 from
+// the complete histogram, remembers it as the next guess and either confirms (writes the selection state
+// exactly as the plain pass's work-group 0 does, *flag = 1: the plain pass that follows returns at once)
+// or voids the speculative output (level-2 histogram and list counters cleared, *flag = 0).
+struct SpecCheckParams {
+    const unsigned long long* hist1; unsigned long long rank;
+    uint32_t* guess; uint32_t* flag;
+    SelState* sel;
+    unsigned long long* hist2;
+    uint32_t* counters;
+};
+template <class Ex>
+SM_HD void k_spec_check(Ex& ex, const SpecCheckParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    unsigned long long* scratch = (unsigned long long*)(ex.lds() + LDS_SCRATCH_FLOATS);
+    uint32_t* res = (uint32_t*)(scratch + nt + 16);             // behind wg_resolve's partials and group totals
+    wg_resolve(ex, st, p.hist1, HIST1_BINS, p.rank, scratch, res);
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid == 0) {
+            const uint32_t g = *p.guess;
+            const uint32_t hit = (g == res[0] + 1u) ? 1u : 0u;
+            res[3] = hit;
+            *p.flag = hit;
+            *p.guess = res[0] + 1u;
+            if (hit) {
+                p.sel->prefix = res[0]; p.sel->level = 1;
+                p.sel->rank = (unsigned long long)res[1] | ((unsigned long long)res[2] << 32);
+                if (p.counters[2]) p.counters[3] = 1u;           // the overflow was real
+            }
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (res[3]) return;
+        for (int b = tid; b < HIST_LO_BINS; b += nt) p.hist2[b] = 0ull;
+        if (tid < 3) p.counters[tid] = 0u;
+    });
 }
 
 // the candidates' share of the Parseval sum once the cull threshold is known (sumsq above)
@@ -2085,16 +2182,6 @@ SM_HD void k_scan(Ex& ex, const ScanParams& p) {
     });
 }
 
-// blend constants (device memory), written by k_slerp_consts
-struct BlendConsts {
-    float thr;        // cutoff threshold (0 when cutoff_pct == 0)
-    float dot;        // clamped cosine between the slerp-class vectors
-    float cos_t, sin_t;
-    float inv_rel;    // 1 / max(||v1 - dot v0||, 1e-12)
-    float pad[3];
-    double s00, s01, s11;
-    unsigned long long n_slerp;
-};
 
 struct ReduceParams {
     const float* reA; const float* reB;

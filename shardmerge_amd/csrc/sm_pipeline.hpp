@@ -131,7 +131,10 @@ SM_KERNEL_TAG(KI1R1, I1Params, "i1_cols_inv", k_i1_r1(ex, p))
 SM_KERNEL_TAG(KPublish, PublishParams, "publish", k_publish(ex, p))
 SM_KERNEL_TAG(KHist, HistParams, "select_hist", k_hist(ex, p))
 SM_KERNEL_TAG(KScan, ScanParams, "select_scan", k_scan(ex, p))
-SM_KERNEL_TAG(KSelect2, Select2Params, "select_lvl2", k_select2(ex, p))
+SM_KERNEL_TAG(KSelect2, Select2Params, "select_lvl2", k_select2<false>(ex, p))
+SM_KERNEL_TAG(KSelect2Cull, Select2Params, "select_lvl2_cull", k_select2<false>(ex, p))     // the cull's pass: returns at once after a confirmed speculation
+SM_KERNEL_TAG(KBlendSel, Select2Params, "blend", k_select2<true>(ex, p))
+SM_KERNEL_TAG(KSpecCheck, SpecCheckParams, "select_spec_check", k_spec_check(ex, p))
 SM_KERNEL_TAG(KSelect3, Select3Params, "select_lvl3_cand", k_select3(ex, p))
 SM_KERNEL_TAG(KReduceCand, ReduceCandParams, "slerp_reduce_cand", k_reduce_cand(ex, p))
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
@@ -250,6 +253,7 @@ class Pipeline {
     uint32_t debug_cand_cap = 0;      // test hook: clamp the candidate-list capacities
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
+    bool spec_cull = true;            // the blend pass speculates on the cull threshold's level-1 bin (k_select2<true>)
     bool dftp_pairs_enabled = true;   // test hook: 0 = the generic k_dftp for every p
     int debug_force_split = 0;        // test hook: split a column length into this many row blocks even if it has a plan
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
@@ -412,7 +416,8 @@ class Pipeline {
     static constexpr size_t PART_DOUBLES = 4 * 65536 + 2 * 40000;
     static constexpr size_t OFF_PART_IM = OFF_PART + PART_DOUBLES * 8;     // sum w (Im a)^2 partials of the role-a producer
     static constexpr size_t PART_IM_DOUBLES = 131072;
-    static constexpr size_t SMALL_BYTES = OFF_PART_IM + PART_IM_DOUBLES * 8;
+    static constexpr size_t OFF_SPEC = OFF_PART_IM + PART_IM_DOUBLES * 8;   // u32 guess[8] (bin + 1, per cull slot), u32 flag
+    static constexpr size_t SMALL_BYTES = OFF_SPEC + 64;
     unsigned long long* d_hist() { return (unsigned long long*)((char*)small_.p + OFF_HIST); }
     unsigned long long* d_hist2() { return d_hist() + HIST1_BINS; }
     unsigned long long* d_hist3() { return d_hist2() + HIST_LO_BINS; }
@@ -431,6 +436,8 @@ class Pipeline {
     double* d_norm2() { return (double*)((char*)small_.p + OFF_NORM2); }
     double* d_part() { return (double*)((char*)small_.p + OFF_PART); }
     double* d_part_im() { return (double*)((char*)small_.p + OFF_PART_IM); }
+    uint32_t* d_spec_guess(int slot) { return (uint32_t*)((char*)small_.p + OFF_SPEC) + (slot < 0 ? 0 : slot > 7 ? 7 : slot); }
+    uint32_t* d_spec_flag() { return (uint32_t*)((char*)small_.p + OFF_SPEC) + 8; }
     // The four working planes come from a pool of equally sized buffers: a pair merge whose
     // result stays in the spectral domain (K >= 3) keeps its Re R / Im a planes as they are - the
     // planes are detached from the working set and fresh ones take their place.
@@ -772,8 +779,10 @@ class Pipeline {
     // A candidate-list overflow sets a sticky flag; the caller then redoes the work with
     // safe_select = true: three plain histogram passes, one scan after each.
     static constexpr int CAND_GRID = 256;
+    // spec_slot >= 0: X came out of run_blend_spec(): k_spec_check decides whether its speculative level-2 work
+    // stands; the plain pass below then returns at once (same grid, so the partials are the same either way)
     void run_select(const Geo& g, const float* X, const float* Y, unsigned long long rank, bool level1_done, float* thr_out,
-                    bool fuse_reduce = false, int* nparts_out = nullptr, bool sumsq = false) {
+                    bool fuse_reduce = false, int* nparts_out = nullptr, bool sumsq = false, int spec_slot = -1) {
         const size_t total = (size_t)g.Cb * g.R;
         HistParams h;
         h.X = X; h.Y = Y; h.R = g.R; h.C = g.Cw; h.Cb = g.Cb; h.vec4 = vec4(g); h.sel = d_sel(0);
@@ -808,7 +817,17 @@ class Pipeline {
         int grid2 = stream_grid((total + 3) / 4, 256, q.chunks);
         while ((size_t)(grid2 + CAND_GRID) * 4 > PART_DOUBLES) { q.chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, q.chunks); }
         const size_t lds2 = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS) * 4 + (size_t)STAGE_PAIRS * sizeof(cf4);
-        be.template launch<KSelect2>(grid2, 256, lds2, q, stream);
+        q.skip = nullptr; q.blendB = nullptr; q.blendR = nullptr; q.consts = nullptr; q.t_sum = 0.f; q.hist1_out = nullptr; q.guess = nullptr;
+        if (spec_slot >= 0) {
+            SpecCheckParams sc;
+            sc.hist1 = d_hist(); sc.rank = rank; sc.guess = d_spec_guess(spec_slot); sc.flag = d_spec_flag();
+            sc.sel = d_sel(0); sc.hist2 = d_hist2(); sc.counters = d_candctr();
+            be.template launch<KSpecCheck>(1, 256, LDS_SCRATCH_FLOATS * 4 + (256 + 16) * 8 + 16, sc, stream);
+            q.skip = d_spec_flag();
+            be.template launch<KSelect2Cull>(grid2, 256, lds2, q, stream);
+        } else {
+            be.template launch<KSelect2>(grid2, 256, lds2, q, stream);
+        }
 
         Select3Params t3;
         t3.cand = q.cand; t3.sel = d_sel(0); t3.hist2 = d_hist2(); t3.hist = d_hist3();
@@ -838,6 +857,39 @@ class Pipeline {
         b.mode = mode; b.agreement = agreement; b.t = t; b.t_sum = t_sum;
         b.consts = d_consts(); b.hist = hist ? d_hist() : nullptr; b.chunks = pick_chunks((total + 3) / 4, 256, 8, 8);
         be.template launch<KBlend>(stream_grid((total + 3) / 4, 256, b.chunks), 256, (LDS_SCRATCH_FLOATS + HIST1_BINS) * 4, b, stream);
+    }
+
+    // SLERP blend + the cull selection's level-2 pass on a guessed level-1 bin, in one sweep (k_select2<true>);
+    // grid and element order are those of the plain selection pass that run_select(..., spec_slot) keeps as fallback
+    void run_blend_spec(const Geo& g, float t_sum, bool sumsq, int spec_slot) {
+        const size_t total = (size_t)g.Cb * g.R;
+        Select2Params q;
+        q.X = plane(g, P_REA); q.Y = nullptr; q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.vec4 = vec4(g); q.sel = d_sel(0);
+        q.hist1 = nullptr; q.rank = 0; q.hist = d_hist2();
+        q.cand = cand_lists(); q.fuse_reduce = 0; q.partials = d_part(); q.sumsq = sumsq ? 1 : 0;
+        q.flush_always = debug_flush_always ? 1 : 0;
+        q.chunks = cull_select_chunks(total);
+        q.skip = nullptr;
+        q.blendB = plane(g, P_REB); q.blendR = plane(g, P_RER); q.consts = d_consts(); q.t_sum = t_sum;
+        q.hist1_out = d_hist(); q.guess = d_spec_guess(spec_slot);
+        const int grid = stream_grid((total + 3) / 4, 256, q.chunks);
+        const size_t lds = (LDS_SCRATCH_FLOATS + HIST_LO_BINS + 8 + STAGE_KEYS + HIST1_BINS) * 4;
+        be.template launch<KBlendSel>(grid, 256, lds, q, stream);
+    }
+    // test hook: did the last k_spec_check confirm the speculation? (-1: none ran on this context yet)
+    long last_spec_verdict() {
+        if (!small_.p) return -1;
+        uint32_t v = 0;
+        be.d2h(&v, d_spec_flag(), sizeof v, stream);
+        be.sync(stream);
+        return (long)v;
+    }
+    // steps per thread of the cull's selection pass (and of the speculative blend in front of it)
+    int cull_select_chunks(size_t total) const {
+        int chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, sel_wgs_per_cu);
+        int grid2 = stream_grid((total + 3) / 4, 256, chunks);
+        while ((size_t)(grid2 + CAND_GRID) * 4 > PART_DOUBLES) { chunks *= 2; grid2 = stream_grid((total + 3) / 4, 256, chunks); }
+        return chunks;
     }
 
     // masked slerp sums + constants (reference functions.py:36-43 on the slerp class).
@@ -985,7 +1037,7 @@ class Pipeline {
     // spectrum-domain part of a pair merge; planes P_REA/P_IMA/P_REB already hold
     // the (scaled) half spectra.  Leaves Re R in P_RER and the cull threshold in d_thr(1).
     void spectral_blend(const Geo& g, int mode, double t, double t_sum, double cutoff_pct, double cull_pct,
-                        int agreement, bool level1_hist_done, bool& have_cull, int* sumsq_parts = nullptr) {
+                        int agreement, bool level1_hist_done, bool& have_cull, int* sumsq_parts = nullptr, int spec_slot = 7) {
         const unsigned long long nfull = (unsigned long long)g.R * g.C * (unsigned long long)g.batch;
         have_cull = false;
         if (mode == BLEND_SLERP) {
@@ -995,11 +1047,13 @@ class Pipeline {
                 run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0),
                            true, &fused);
             run_slerp_consts(g, have_cut, (float)t, fused);
-            run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
+            const bool spec = cull_pct > 0 && spec_cull && !safe_select && !g.full;
+            if (spec) run_blend_spec(g, (float)t_sum, sumsq_parts != nullptr, spec_slot);
+            else run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
             if (sumsq_parts) *sumsq_parts = 0;
             if (cull_pct > 0) {
                 run_select(g, plane(g, P_RER), nullptr, pct_index(nfull, cull_pct), true, d_thr(1), false, sumsq_parts,
-                           sumsq_parts != nullptr);
+                           sumsq_parts != nullptr, spec ? spec_slot : -1);
                 have_cull = true;
             }
         } else {
@@ -1468,6 +1522,7 @@ class Pipeline {
         }
         noise_seed_ = 0;                         // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
+        int round_idx = 0;                       // tournament round: the cull fraction (and its speculation slot) goes with it
         int deferred_step = -1;
         bool deferred_cut = false, deferred_cull = false;
         while (stack.size() > 1) {
@@ -1613,7 +1668,7 @@ class Pipeline {
                         int sel_parts = 0;
                         const bool fused_norm = im_parts > 0 && !safe_select && cull_pct > 0;
                         spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull,
-                                       fused_norm ? &sel_parts : nullptr);
+                                       fused_norm ? &sel_parts : nullptr, std::min(round_idx, 6));
                         for (int side = 0; side < 2; ++side) {          // consumed spectral inputs give their planes back
                             Slot& in = side == 0 ? stack[x] : stack[y];
                             if (in.spectral) { pool_release(in.re_id); pool_release(in.im_id); in.re_id = in.im_id = -1; }
@@ -1681,6 +1736,7 @@ class Pipeline {
             }
             stack.swap(next);
             cull_pct = cull_pct / 2.0;
+            ++round_idx;
             if (last_round) break;
         }
         rp.n_steps = std::min(step, (int)SMHIP_MAX_PAIRS);

@@ -601,3 +601,40 @@ def test_generic_dft_kernel_agrees_with_the_paired_one(engine):
             assert pc.spectral_residual(fast[2], slow[2])[1] < 2e-6
         else:
             assert so.rel_err(fast[2], slow[2]) < 3e-2
+
+
+@pytest.mark.parametrize("k,shape", [(2, (128, 256)), (3, (256, 128)), (2, (63, 40)), (2, (3, 64, 128))],
+                         ids=["k2", "k3", "k2_unaligned", "k2_rank3"])
+def test_speculative_cull_selection_never_changes_a_bit(engine, k, shape):
+    """The SLERP blend guesses the level-1 bin of the cull threshold (what it was the last time this tournament
+    round ran) and does the cull selection's level-2 pass in the same sweep; k_spec_check confirms or voids
+    it.  Confirmed, voided and switched off must give the same bits - outputs, thresholds, norms."""
+    from oracle import spectral_oracle as so
+    base, fts = _layer_inputs(shape, k, 77)
+    args = (fts, [base] * k, so.ALPHAS[:k], base)
+    engine.ctx.debug_option("spec_cull", 0)
+    try:
+        off = engine.merge_layer(*args, want_delta=True)
+    finally:
+        engine.ctx.debug_option("spec_cull", 1)
+    # a different cull fraction moves the threshold into another bin: the next guess is wrong
+    engine.merge_layer(*args, cull_start_pct=0.45)
+    miss = engine.merge_layer(*args, want_delta=True)
+    assert engine.ctx.debug_query("spec_hit") == 0 or k == 3      # (K = 3: the verdict read is the LAST round's)
+    hit = engine.merge_layer(*args, want_delta=True)
+    assert engine.ctx.debug_query("spec_hit") == 1
+    for other in (miss, hit):
+        assert torch.equal(other[0].view(torch.int16), off[0].view(torch.int16))
+        assert torch.equal(other[2], off[2])
+        assert other[1].branches == off[1].branches and other[1].delta_norms == off[1].delta_norms
+        for a, b in zip(other[1].infos, off[1].infos):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert (a.cutoff_threshold, a.cull_threshold, a.n_slerp, a.dot) == (b.cutoff_threshold, b.cull_threshold, b.n_slerp, b.dot)
+    # ... and the candidate-list overflow on a confirmed guess still falls back to the full-pass selection
+    engine.ctx.debug_option("cand_cap", 7)
+    try:
+        capped = engine.merge_layer(*args, want_delta=True)
+    finally:
+        engine.ctx.debug_option("cand_cap", 0)
+    assert torch.equal(capped[0].view(torch.int16), off[0].view(torch.int16))

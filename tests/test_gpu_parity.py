@@ -609,3 +609,9 @@ def test_llama2_and_qwen2_mlp_shapes_k2_vs_exact_norm_oracle(engine, shape):
 
 def test_generic_dft_kernel_on_device(engine):
     emul_tier.test_generic_dft_kernel_agrees_with_the_paired_one(engine)
+
+
+@pytest.mark.parametrize("k,shape", [(2, (128, 256)), (3, (256, 128)), (2, (63, 40)), (2, (3, 64, 128))],
+                         ids=["k2", "k3", "k2_unaligned", "k2_rank3"])
+def test_speculative_cull_selection_on_device(engine, k, shape):
+    emul_tier.test_speculative_cull_selection_never_changes_a_bit(engine, k, shape)

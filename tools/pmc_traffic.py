@@ -40,7 +40,7 @@ NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI
          "KI1x1Q": "i1_cols_inv", "KI1x2Q": "i1_cols_inv", "KSpecNorm": "spec_norm", "KSpecRescale": "spec_rescale",
          "KDeltaNorms": "delta_norms", "KAddition": "addition_merge", "KSerialNorm": "serial_norm",
          "KDftp": "dft_across_slices", "KDftpPairs": "dft_across_slices", "KTranspose": "transpose",
-         "KSelect2": "select_lvl2", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
+         "KSelect2": "select_lvl2", "KSelect2Cull": "select_lvl2_cull", "KBlendSel": "blend", "KSpecCheck": "select_spec_check", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
 
 
 def main():
