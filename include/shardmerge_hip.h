@@ -168,7 +168,7 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
  *      "force_split" = p splits the column length of smhip_merge_layer into p row blocks (the path of
  *      lengths without a plan, smhip_shape_supported) although it has one, 0 = off;
  *      "spec_cull" = 0 keeps the SLERP blend and the cull's selection pass apart (no speculation on the
- *      threshold's level-1 bin);
+ *      threshold's level-1 bin); "spec_min_bins" = the smallest spectrum (bins) that speculates (default 2^20);
  *      "dftp_pairs" = 0 runs the generic p-point DFT kernel also for p <= 126;
  *      "sel_wgs_per_cu" the resident work-groups per CU its grid is sized for (0 = default 5), and
  *      "sel_flush_always" flushes its staged candidates after every round (the

@@ -254,6 +254,7 @@ class Pipeline {
     uint32_t debug_sel_chunks = 0;    // test hook: steps per thread of the level-2 selection pass (0 = automatic)
     bool debug_flush_always = false;  // test hook: flush staged candidates after every round
     bool spec_cull = true;            // the blend pass speculates on the cull threshold's level-1 bin (k_select2<true>)
+    size_t spec_min_bins = 1 << 20;   // ... from this many spectrum bins on (below, its two extra launches cost more than the pass)
     bool dftp_pairs_enabled = true;   // test hook: 0 = the generic k_dftp for every p
     int debug_force_split = 0;        // test hook: split a column length into this many row blocks even if it has a plan
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
@@ -1047,7 +1048,7 @@ class Pipeline {
                 run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0),
                            true, &fused);
             run_slerp_consts(g, have_cut, (float)t, fused);
-            const bool spec = cull_pct > 0 && spec_cull && !safe_select && !g.full;
+            const bool spec = cull_pct > 0 && spec_cull && !safe_select && !g.full && (size_t)g.Cb * g.R >= spec_min_bins;
             if (spec) run_blend_spec(g, (float)t_sum, sumsq_parts != nullptr, spec_slot);
             else run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
             if (sumsq_parts) *sumsq_parts = 0;

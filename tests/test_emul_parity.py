@@ -617,6 +617,14 @@ def test_speculative_cull_selection_never_changes_a_bit(engine, k, shape):
         off = engine.merge_layer(*args, want_delta=True)
     finally:
         engine.ctx.debug_option("spec_cull", 1)
+    engine.ctx.debug_option("spec_min_bins", 0)          # (small spectra do not speculate by default)
+    try:
+        _speculation_checks(engine, args, off, k)
+    finally:
+        engine.ctx.debug_option("spec_min_bins", -1)
+
+
+def _speculation_checks(engine, args, off, k):
     # a different cull fraction moves the threshold into another bin: the next guess is wrong
     engine.merge_layer(*args, cull_start_pct=0.45)
     miss = engine.merge_layer(*args, want_delta=True)
