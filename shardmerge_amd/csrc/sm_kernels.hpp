@@ -3450,17 +3450,17 @@ SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
     }
 }
 
-// [R][C] -> [C][R], elements of 2 or 4 bytes moved as bits (32 x 32 tiles through LDS): a tensor
+// [R][C] -> [C][R], elements of 2 or 4 bytes moved as bits (64 x 64 tiles through LDS): a tensor
 // whose ROW length is the rough one is merged transposed (fft2 commutes with the transpose and
 // every statistic of the merge is a sum or an order statistic over all bins)
-constexpr int TR_TILE = 32;
+constexpr int TR_TILE = 64;         // 64 two-byte elements = one 128-byte line per tile row, both ways
 struct TransposeParams { const void* src; void* dst; int R, C; int esize; };
 template <class Ex>
 SM_HD void k_transpose(Ex& ex, const TransposeParams& p) {
     typename Ex::template State<EmptyState> st;
     ex.init(st);
     const int nt = ex.nthreads();
-    uint32_t* tile = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);   // [32][33]
+    uint32_t* tile = (uint32_t*)(ex.lds() + LDS_SCRATCH_FLOATS);   // [TR_TILE][TR_TILE + 1]
     const int tc = (p.C + TR_TILE - 1) / TR_TILE;
     const int r0 = (ex.bid() / tc) * TR_TILE, c0 = (ex.bid() % tc) * TR_TILE;
     ex.each(st, [&](int tid, EmptyState&) {
