@@ -167,6 +167,7 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
  *      "force_split" = p splits the column length of smhip_merge_layer into p row blocks (the path of
  *      lengths without a plan, smhip_shape_supported) although it has one, 0 = off;
+ *      "pair1d" = 0 sends 1-D tensors through the multi-kernel pipeline instead of the one-launch pair merge;
  *      "spec_cull" = 0 keeps the SLERP blend and the cull's selection pass apart (no speculation on the
  *      threshold's level-1 bin); "spec_min_bins" = the smallest spectrum (bins) that speculates (default 2^20);
  *      "dftp_pairs" = 0 runs the generic p-point DFT kernel also for p <= 126;

@@ -3244,6 +3244,277 @@ SM_HD void k_cull(Ex& ex, const CullParams& p) {
 
 
 // =====================================================================
+// A whole SLERP pair merge of two 1-D tensors in ONE work-group (R = 1, C <= PAIR1D_MAX_C): row
+// transform (two-for-one), Hermitian split, both order statistics (three-level radix select in
+// LDS), slerp sums and constants, blend, cull, inverse transform, scale / add-back / cast.  The
+// multi-kernel pipeline spends ~25 launches (0.25 ms of launch latency) on such a tensor - every
+// norm weight of a model.  Same arithmetic, same exact thresholds; sums in another order.
+// =====================================================================
+constexpr int PAIR1D_MAX_C = 8192;
+struct Pair1dParams {
+    FftPlanDev plan;            // N = C
+    SigDesc a, b;               // role a = the larger-norm input
+    int C;
+    float sa, sb;               // 1 / ||a||, 1 / ||b||
+    float t, t_sum;
+    unsigned long long rank_cut; int have_cut;
+    unsigned long long rank_cull; int have_cull;
+    I2Params fin;               // inv_n, post, ifft_policy, base, out, flags, norm_partials (plan / G unused)
+    float* thr;                 // [2]: cutoff and cull thresholds (device, as the selection passes leave them)
+    BlendConsts* consts;
+};
+
+// k-th smallest (0-based, with multiplicities w) of the keys a thread holds: keys[j] for j < nk, two key
+// sets (x: always, y: optional).  11 + 10 + 10 bits, histograms in LDS; every thread returns the key.
+template <class Ex, class StT, class KeyFn>
+SM_HD uint32_t wg_select_lds(Ex& ex, StT& st, uint32_t* hist, uint32_t* part, uint32_t* ctl, unsigned long long rank,
+                             int per_thread, KeyFn keys) {
+    using S = typename StT::value_type;
+    const int nt = ex.nthreads();
+    uint32_t prefix = 0;
+    int prefix_bits = 0;
+    unsigned long long r = rank;
+    for (int level = 0; level < 3; ++level) {
+        const int bits = level == 0 ? 11 : 10;
+        const int nbins = 1 << bits;
+        const int shift = 31 - prefix_bits - bits;
+        ex.each(st, [&](int tid, S&) { for (int b = tid; b < nbins; b += nt) hist[b] = 0; });
+        ex.sync();
+        ex.each(st, [&](int tid, S& s) {
+            for (int j = 0; j < per_thread; ++j) {
+                uint32_t key[2], w;
+                const int n = keys(tid, s, j, key, w);
+                for (int e = 0; e < n; ++e)
+                    if (prefix_bits == 0 || (key[e] >> (31 - prefix_bits)) == prefix)
+                        ex.lds_atomic_add(&hist[(key[e] >> shift) & (uint32_t)(nbins - 1)], w);
+            }
+        });
+        ex.sync();
+        const int per = (nbins + nt - 1) / nt;
+        const int ngrp = (nt + 15) / 16;
+        uint32_t* grp = part + nt;                     // group totals of 16 threads' partials (counts fit 32 bits)
+        ex.each(st, [&](int tid, S&) {
+            uint32_t sum = 0;
+            for (int q = 0; q < per; ++q) { const int b = tid * per + q; if (b < nbins) sum += hist[b]; }
+            part[tid] = sum;
+        });
+        ex.sync();
+        ex.each(st, [&](int tid, S&) {
+            if (tid >= ngrp) return;
+            uint32_t g = 0;
+            for (int q = 0; q < 16; ++q) { const int i = tid * 16 + q; if (i < nt) g += part[i]; }
+            grp[tid] = g;
+        });
+        ex.sync();
+        // every thread finds where its own bins start (a few independent LDS reads); the one whose range
+        // holds the rank walks its bins
+        ex.each(st, [&](int tid, S&) {
+            uint32_t excl = 0, total = 0;
+            const int g0 = tid / 16;
+            for (int g = 0; g < ngrp; ++g) { const uint32_t v = grp[g]; total += v; if (g < g0) excl += v; }
+            for (int q = g0 * 16; q < tid; ++q) excl += part[q];
+            if (total == 0) { if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; } return; }
+            const uint32_t rr = r >= (unsigned long long)total ? total - 1u : (uint32_t)r;
+            const uint32_t mine = part[tid];
+            if (rr >= excl && rr - excl < mine) {
+                uint32_t cum = excl;
+                int b = tid * per;
+                while (b < nbins - 1 && cum + hist[b] <= rr) { cum += hist[b]; ++b; }
+                ctl[0] = (uint32_t)b; ctl[1] = rr - cum; ctl[2] = 0u;
+            }
+        });
+        ex.sync();
+        prefix = (prefix << bits) | ctl[0];
+        prefix_bits += bits;
+        r = (unsigned long long)ctl[1] | ((unsigned long long)ctl[2] << 32);
+        ex.sync();
+    }
+    return prefix;
+}
+
+template <class P, class Ex>
+SM_HD void k_pair1d(Ex& ex, const Pair1dParams& p) {
+    typename Ex::template State<FftState> st;
+    ex.init(st);
+    const FftPlanDev& pl = p.plan;
+    const int T = plan_T<P>(pl), C = plan_N<P>(pl);
+    const int LF = plan_lds<P>(pl);
+    const int Cb = C / 2 + 1;
+    float* fftbuf = ex.lds() + LDS_SCRATCH_FLOATS;
+    float* zr = fftbuf + LF;
+    float* zi = zr + C;
+    uint32_t* hist = (uint32_t*)(zi + C);
+    uint32_t* part = hist + HIST1_BINS;             // nt words + nt / 16 group totals
+    uint32_t* ctl = part + 1024 + 64;               // 8 words + the constants broadcast
+    float* cbuf = (float*)(ctl + 8);
+    const int QB = (Cb + T - 1) / T;                // bins per thread (<= EMAX / 2 + 1)
+
+    // ---- forward: z = a + i b, one C-point transform, split by Hermitian symmetry ----
+    // (straight-line on purpose: wrapping the two transforms / the two selections into loops to share
+    //  their code made the 8192-point kernel spill 378 registers and 50 % slower)
+    ex.each(st, [&](int tid, FftState& s) {
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) {
+            const int n = tid + q * T;
+            s.xr[q] = n < C ? load_sig1(p.a, (size_t)n) : 0.f;
+            s.xi[q] = n < C ? load_sig1(p.b, (size_t)n) : 0.f;
+        }
+    });
+    auto nat_scatter = [&](int tid, FftState& s, auto comp_c) {
+        constexpr int comp = decltype(comp_c)::value;
+        const float* x = comp_of<comp>(s);
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) { const int n = tid + q * T; if (n < C) fftbuf[lpad(n)] = x[q]; }
+    };
+    auto fin_gather = [&](int tid, FftState& s, auto comp_c) {
+        constexpr int comp = decltype(comp_c)::value;
+        float* o = comp_of<comp>(s);
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) { const int k = tid + q * T; if (k < C) o[q] = fftbuf[lpad(k)]; }
+    };
+    wg_fft<P>(ex, st, pl, fftbuf, nat_scatter, fin_gather);
+    ex.each(st, [&](int tid, FftState& s) {
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) { const int k = tid + q * T; if (k < C) { zr[k] = s.xr[q]; zi[k] = s.xi[q]; } }
+    });
+    ex.sync();
+    // bins k = tid + q T (q < QB): Re a -> xr[q], Im a -> xi[q], Re b -> xr[EMAX/2 + 1 + q]   (QB <= EMAX/2 + 1)
+    constexpr int RB0 = EMAX / 2 + 1;
+    ex.each(st, [&](int tid, FftState& s) {
+        for (int q = 0; q < QB; ++q) {
+            const int k = tid + q * T;
+            float ra = 0.f, ia = 0.f, rb = 0.f;
+            if (k < Cb) {
+                const int m = (C - k) % C;
+                const float r1 = zr[k], i1 = zi[k], r2 = zr[m], i2 = zi[m];
+                ra = 0.5f * (r1 + r2) * p.sa; ia = 0.5f * (i1 - i2) * p.sa;
+                rb = 0.5f * (i1 + i2) * p.sb;
+            }
+            s.xr[q] = ra; s.xi[q] = ia; s.xr[RB0 + q] = rb;
+        }
+    });
+    ex.sync();
+
+    // ---- cutoff threshold over |Re a| and |Re b| (functions.py:115-119) ----
+    float thr0 = 0.f;
+    if (p.have_cut) {
+        const uint32_t key = wg_select_lds(ex, st, hist, part, ctl, p.rank_cut, QB,
+            [&](int tid, FftState& s, int q, uint32_t* key2, uint32_t& w) {
+                const int k = tid + q * T;
+                if (k >= Cb) return 0;
+                w = (uint32_t)bin_weight(k, C);
+                key2[0] = f2u(s.xr[q]) & 0x7fffffffu; key2[1] = f2u(s.xr[RB0 + q]) & 0x7fffffffu;
+                return 2;
+            });
+        thr0 = u2f(key);
+    }
+    // ---- slerp-class sums and constants (functions.py:36-43) ----
+    ex.each(st, [&](int tid, FftState& s) {
+        double s00 = 0, s01 = 0, s11 = 0, cnt = 0;
+        for (int q = 0; q < QB; ++q) {
+            const int k = tid + q * T;
+            if (k >= Cb) continue;
+            const float a = s.xr[q], b = s.xr[RB0 + q];
+            if (same_sign(a, b) && !(fabsf(b) < thr0)) {
+                const double w = (double)bin_weight(k, C);
+                s00 += w * (double)(a * a); s01 += w * (double)(a * b); s11 += w * (double)(b * b); cnt += w;
+            }
+        }
+        s.red[0] = s00; s.red[1] = s01; s.red[2] = s11; s.red[3] = cnt;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        const double s00 = tot[0], s01 = tot[1], s11 = tot[2], cnt = tot[3];
+        BlendConsts c;
+        c.thr = thr0;
+        c.s00 = s00; c.s01 = s01; c.s11 = s11; c.n_slerp = (unsigned long long)cnt;
+        double dot = s01 / (sqrt(s00) * sqrt(s11));
+        if (dot > 1.0) dot = 1.0;
+        if (dot < -1.0) dot = -1.0;
+        const float dotf = (float)dot;
+        const float theta = acosf(dotf) * p.t;
+        double rel2 = s11 - 2.0 * (double)dotf * s01 + (double)dotf * (double)dotf * s00;
+        if (rel2 < 0) rel2 = 0;
+        double reln = sqrt(rel2);
+        if (reln < 1e-12) reln = 1e-12;
+        c.dot = dotf; c.cos_t = cosf(theta); c.sin_t = sinf(theta); c.inv_rel = (float)(1.0 / reln);
+        c.pad[0] = c.pad[1] = c.pad[2] = 0.f;
+        *p.consts = c;
+        p.thr[0] = thr0;
+        cbuf[0] = c.dot; cbuf[1] = c.cos_t; cbuf[2] = c.sin_t; cbuf[3] = c.inv_rel;
+    });
+    BlendConsts bc;
+    memset(&bc, 0, sizeof bc);
+    bc.thr = thr0; bc.dot = cbuf[0]; bc.cos_t = cbuf[1]; bc.sin_t = cbuf[2]; bc.inv_rel = cbuf[3];
+    // ---- blend (functions.py:121-145), cull threshold over |Re R| (:146-147) ----
+    ex.each(st, [&](int tid, FftState& s) {
+        for (int q = 0; q < QB; ++q) {
+            const int k = tid + q * T;
+            if (k < Cb) s.xr[q] = blend_slerp_one(bc, p.t_sum, s.xr[q], s.xr[RB0 + q]);
+        }
+    });
+    ex.sync();
+    float thr1 = 0.f;
+    if (p.have_cull) {
+        const uint32_t key = wg_select_lds(ex, st, hist, part, ctl, p.rank_cull, QB,
+            [&](int tid, FftState& s, int q, uint32_t* key2, uint32_t& w) {
+                const int k = tid + q * T;
+                if (k >= Cb) return 0;
+                w = (uint32_t)bin_weight(k, C);
+                key2[0] = f2u(s.xr[q]) & 0x7fffffffu;
+                return 1;
+            });
+        thr1 = u2f(key);
+    }
+    // ---- inverse: Hermitian extension of (Re R culled, Im a), swap trick, one C-point transform ----
+    ex.each(st, [&](int tid, FftState& s) {
+        if (tid == 0) p.thr[1] = thr1;
+        for (int q = 0; q < QB; ++q) {
+            const int k = tid + q * T;
+            if (k < Cb) { float r = s.xr[q]; if (fabsf(r) < thr1) r = 0.f; zr[k] = r; zi[k] = s.xi[q]; }
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, FftState& s) {
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) {
+            const int n = tid + q * T;
+            float re = 0.f, im = 0.f;
+            if (n < C) {
+                if (n < Cb) { re = zr[n]; im = zi[n]; }
+                else { re = zr[C - n]; im = -zi[C - n]; }
+            }
+            s.xr[q] = im; s.xi[q] = re;             // ifft(x) = swap(fft(swap(x)))
+        }
+    });
+    ex.sync();
+    wg_fft<P>(ex, st, pl, fftbuf, nat_scatter, fin_gather);
+    ex.each(st, [&](int tid, FftState& s) {
+        uint32_t nan1 = 0, inf1 = 0, nan2 = 0, inf2 = 0;
+        double ss = 0.0;
+#pragma unroll
+        for (int q = 0; q < EMAX; ++q) {
+            const int n = tid + q * T;
+            if (n < C) {
+                float v;
+                i2_finish(p.fin, s.xi[q], (size_t)n, nan1, inf1, nan2, inf2, v);
+                ss += (double)v * v;
+                if (p.fin.out_mode == OUT_BF16) ((uint16_t*)p.fin.out)[n] = f_to_bf16(v);
+                else ((float*)p.fin.out)[n] = v;
+            }
+        }
+        if (nan1) ex.global_atomic_add_u32(&p.fin.flags[0], nan1);
+        if (inf1) ex.global_atomic_or_u32(&p.fin.flags[1], 1u);
+        if (nan2) ex.global_atomic_add_u32(&p.fin.flags[2], nan2);
+        if (inf2) ex.global_atomic_or_u32(&p.fin.flags[3], 1u);
+        s.red[0] = ss; s.red[1] = 0.0;
+    });
+    if (p.fin.norm_partials) {
+        ex.sync();
+        ex.template block_sum<2>(st, [&](const double* tot) { p.fin.norm_partials[0] = tot[0]; p.fin.norm_partials[1] = 0.0; });
+    }
+}
+
+// =====================================================================
 // Long / rough column lengths: R = p * M with M a length the work-group engine plans
 // (even) and p <= DFTP_MAX_P anything (43 for the 11008 of Llama-2-7B, 37 for the 18944 of
 // Qwen2-7B, 2 for 65536 ...).  Decimation in frequency with n = n1 + M n2, k = p k1 + k2:

@@ -53,6 +53,7 @@ SM_FFT_KERNEL_TAG(KF2Q, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>(), true>(ex
 SM_FFT_KERNEL_TAG(KF2SQ, F2SParams, "f2s_cols_fwd1", (k_f2s<P, f2s_groups<P>(), true>(ex, p)), f2s_groups<P>(), 4)
 SM_FFT_KERNEL_TAG(KI1x1Q, I1Params, "i1_cols_inv", (k_i1<P, 1, true>(ex, p)), 1, 4)
 SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(ex, p)), i1_bins<P>(), 4)
+SM_FFT_KERNEL_TAG(KPair1d, Pair1dParams, "pair_1d", k_pair1d<P>(ex, p), 1, 1)      // one work-group per launch: all the registers it wants
 
 // lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
 // the 3/5/7 * 2^k hidden and MLP sizes of other common models, and 256 / 512: the row blocks of the
@@ -1062,6 +1063,38 @@ class Pipeline {
         }
     }
 
+    // ---- a whole SLERP pair merge of 1-D tensors in one launch (k_pair1d) ------------------------------
+    bool pair1d_enabled = true;
+    bool pair1d_ok(const Geo& g) const {
+        return pair1d_enabled && g.R == 1 && g.batch == 1 && !g.full && g.C >= 2 && g.C <= PAIR1D_MAX_C;
+    }
+    // A = the larger-norm input.  Leaves the thresholds in d_thr(0/1) and the constants in d_consts() as the
+    // multi-kernel path does; norm_parts (optional): one [2] partial of the stored values' squares in d_part()
+    int run_pair1d(const Geo& g, const SigDesc& A, const SigDesc& Bs, double na, double nb, double t, double t_sum,
+                   double cutoff_pct, double cull_pct, const PairOut& o, int* norm_parts) {
+        Pair1dParams q;
+        int rc = get_plan(g.C, q.plan);
+        if (rc) return rc;
+        q.a = A; q.b = Bs; q.C = g.C;
+        q.sa = (float)(1.0 / na); q.sb = (float)(1.0 / nb);
+        q.t = (float)t; q.t_sum = (float)t_sum;
+        const unsigned long long nfull = (unsigned long long)g.C;
+        q.have_cut = cutoff_pct > 0; q.rank_cut = pct_index(2 * nfull, cutoff_pct);
+        q.have_cull = cull_pct > 0; q.rank_cull = pct_index(nfull, cull_pct);
+        memset(&q.fin, 0, sizeof q.fin);
+        q.fin.R = 1; q.fin.C = g.C; q.fin.Cb = g.C / 2 + 1;
+        q.fin.inv_n = (float)(1.0 / (double)g.C);
+        q.fin.ifft_policy = o.ifft_policy; q.fin.post = o.post;
+        q.fin.base = o.base; q.fin.base_dtype = o.base_dtype; q.fin.out = o.out; q.fin.out_mode = o.out_mode;
+        q.fin.flags = d_flags();
+        q.fin.norm_partials = norm_parts ? d_part() : nullptr;
+        if (norm_parts) *norm_parts = 1;
+        q.thr = d_thr(0); q.consts = d_consts();
+        const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)q.plan.lds_floats + 2 * (size_t)g.C + HIST1_BINS + 1024 + 64 + 16) * 4;
+        launch_fft<KPair1d>(q.plan, 1, q.plan.T, lds, q);
+        return SMHIP_OK;
+    }
+
     // ---- A9: merge_tensors_fft2_slerp on fp32 inputs ---------------------------------
     int merge_pair_slerp(const float* v0, const float* v1, int R, int C, double t, double bthr, double t_sum,
                          double cutoff_pct, double cull_pct, float* out, double* n0o, double* n1o, int* branch,
@@ -1634,7 +1667,10 @@ class Pipeline {
                         int im_parts = -1;
                         const bool any_spec = stack[x].spectral || stack[y].spectral ||
                                               (stack[x].rows_id >= 0 && stack[y].rows_id >= 0);
-                        if (!any_spec) {
+                        const bool fused1d = !any_spec && pair1d_ok(g);       // 1-D: the whole pair merge is one launch
+                        if (fused1d) {
+                            f1_ready = false;
+                        } else if (!any_spec) {
                             if (!(f1_ready && d.k == 2)) {
                                 int grid;
                                 if ((rc = run_f1(g, stack[x].sig, stack[y].sig, grid))) return rc;
@@ -1668,8 +1704,9 @@ class Pipeline {
                         bool have_cull;
                         int sel_parts = 0;
                         const bool fused_norm = im_parts > 0 && !safe_select && cull_pct > 0;
-                        spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull,
-                                       fused_norm ? &sel_parts : nullptr, std::min(round_idx, 6));
+                        if (fused1d) have_cull = cull_pct > 0;
+                        else spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull,
+                                            fused_norm ? &sel_parts : nullptr, std::min(round_idx, 6));
                         for (int side = 0; side < 2; ++side) {          // consumed spectral inputs give their planes back
                             Slot& in = side == 0 ? stack[x] : stack[y];
                             if (in.spectral) { pool_release(in.re_id); pool_release(in.im_id); in.re_id = in.im_id = -1; }
@@ -1699,6 +1736,10 @@ class Pipeline {
                         ps.post = (float)target_norm;                       // merged * target_norm (fast_fourier.py:243)
                         float* dtmp = nullptr;
                         if (last_round && delta_out) { ps = PairOut(); ps.out = delta_out; ps.post = (float)target_norm; dtmp = delta_out; }
+                        if (fused1d) {
+                            if ((rc = run_pair1d(g, A.sig, Bs.sig, na, nb, t, d.t_sum, d.cutoff_pct, cull_pct, ps,
+                                                 last_round ? nullptr : &inv_grid))) return rc;
+                        } else
                         if ((rc = run_inverse(g, plane(g, P_RER), plane(g, P_IMA), have_cull ? d_thr(1) : nullptr, ps,
                                               last_round ? nullptr : &inv_grid))) return rc;
                         if (dtmp) {

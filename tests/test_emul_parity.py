@@ -646,3 +646,60 @@ def _speculation_checks(engine, args, off, k):
     finally:
         engine.ctx.debug_option("cand_cap", 0)
     assert torch.equal(capped[0].view(torch.int16), off[0].view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(256,), (1000,), (4096,), (1, 512), (8192,), (77,), (6144,)], ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_pair_merge_of_1d_tensors(engine, shape):
+    """1-D tensors (every norm weight of a model) take k_pair1d: the whole SLERP pair merge - transform,
+    split, both order statistics, slerp constants, blend, cull, inverse, add-back - in one work-group
+    instead of ~25 launches.  Same bar as the multi-kernel pipeline, and the same thresholds as it."""
+    from oracle import spectral_oracle as so
+    base, fts = _layer_inputs(shape, 2, 400)
+    tr = so.LayerTrace()
+    ref = so.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, trace=tr)
+    eng_out = engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, want_delta=True)
+    engine.ctx.debug_option("pair1d", 0)
+    try:
+        multi = engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, want_delta=True)
+    finally:
+        engine.ctx.debug_option("pair1d", 1)
+    out, rep, delta = eng_out
+    pc.check_layer_steps(rep, tr, out.numel())
+    assert rep.branches == ["slerp"]
+    assert pc.spectral_residual(delta, tr.merged_delta)[1] < 2e-6 and so.rel_err(out.float(), ref.float()) < 8.0 / out.numel() ** 0.5
+    a, b = rep.infos[0], multi[1].infos[0]
+    # the two paths round their spectra differently (Hermitian split before / after the scaling): ulps
+    assert abs(a.cutoff_threshold - b.cutoff_threshold) <= 1e-5 * b.cutoff_threshold and abs(a.n_slerp - b.n_slerp) <= 2
+    assert abs(a.cull_threshold - b.cull_threshold) <= 1e-5 * b.cull_threshold and abs(a.dot - b.dot) < 1e-5
+    assert pc.spectral_residual(delta, multi[2])[1] < 1e-6
+    # K = 3 / 4: the tournament around it (fp32 intermediates, the next round's norm from the kernel's own partial)
+    for k in (3, 4):
+        base, fts = _layer_inputs(shape, k, 401 + k)
+        tr = so.LayerTrace()
+        ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
+        out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True)
+        assert rep.branches == tr.branches and [(s[0], s[1]) for s in rep.steps] == tr.pairs
+        # first-round pairs merge raw deltas: thresholds as tight as at K = 2 (later rounds: the chaos floor)
+        first = [i for i, bt in enumerate(tr.steps) if bt is not None][0]
+        assert abs(rep.infos[first].cutoff_threshold - tr.steps[first].cutoff_threshold) <= max(1e-5, 8.0 / out.numel()) * tr.steps[first].cutoff_threshold
+        assert abs(rep.infos[first].n_slerp - tr.steps[first].n_slerp) <= 4
+        assert abs(rep.target_norm - tr.target_norm) <= 2e-6 * tr.target_norm
+        assert so.rel_err(out.float(), ref.float()) < (1e-2 if k == 3 else 8e-2)      # manifest layer_self_floor x 2.5
+
+
+def test_1d_policies_through_the_one_launch_kernel(engine):
+    """NaN -> 0 counts and the Inf error of the inverse transform / add-back, no cull, no cutoff, unaligned views"""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(3)
+    base = (torch.randn(1024 + 3, generator=g) * 0.02).to(torch.bfloat16)[3:]          # 6-byte offset: unaligned
+    fts = [(base.float() + torch.randn(1024, generator=g) * s_).to(torch.bfloat16) for s_ in (0.002, 0.003)]
+    for kw in ({}, {"cull_start_pct": 0.0}, {"cutoff_pct": 0.0}, {"cutoff_pct": 0.0, "cull_start_pct": 0.0}):
+        tr = so.LayerTrace()
+        okw = dict(kw)
+        ref = so.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, trace=tr, **okw)
+        out, rep, delta = engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], base, want_delta=True, **kw)
+        assert pc.spectral_residual(delta, tr.merged_delta)[1] < 2e-6, kw
+    big = base.clone()
+    big[5] = float("inf")
+    with pytest.raises(ValueError):
+        engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], big)

@@ -615,3 +615,12 @@ def test_generic_dft_kernel_on_device(engine):
                          ids=["k2", "k3", "k2_unaligned", "k2_rank3"])
 def test_speculative_cull_selection_on_device(engine, k, shape):
     emul_tier.test_speculative_cull_selection_never_changes_a_bit(engine, k, shape)
+
+
+@pytest.mark.parametrize("shape", [(256,), (1000,), (4096,), (1, 512), (8192,), (77,), (6144,)], ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_pair_merge_of_1d_tensors_on_device(engine, shape):
+    emul_tier.test_one_launch_pair_merge_of_1d_tensors(engine, shape)
+
+
+def test_1d_policies_through_the_one_launch_kernel_on_device(engine):
+    emul_tier.test_1d_policies_through_the_one_launch_kernel(engine)
