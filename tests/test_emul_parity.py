@@ -478,11 +478,11 @@ def _layer_inputs(shape, k, seed):
     return base, fts
 
 
-@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64), (668, 32)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("k", [2, 3])
 def test_column_length_without_a_plan_is_split_into_row_blocks(engine, shape, k):
     """A column length with a prime factor > 13 (11008 = 43 * 256 of Llama-2-7B, 18944 = 37 * 512 of
-    Qwen2-7B; here 34 = 17 * 2, 136 = 17 * 8, 76 = 19 * 4, 172 = 43 * 4, 272 = 17 * 16) is merged as p row blocks of M
+    Qwen2-7B; here 34 = 17 * 2, 136 = 17 * 8, 76 = 19 * 4, 172 = 43 * 4, 272 = 17 * 16, 668 = 167 * 4: p > 126 takes the generic k_dftp) is merged as p row blocks of M
     rows that k_dftp combines (sm_kernels.hpp) - same bar as any other length."""
     from oracle import spectral_oracle as so
     assert engine.lib.shape_supported(*shape) and not engine.lib.length_supported(shape[0])

@@ -555,7 +555,7 @@ def test_correlate_pairs_on_device(engine, golden, case):
 
 
 # ---- column / row lengths without a work-group plan (k_dftp, transposed merge) ------------------------
-@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(34, 64), (136, 96), (76, 96), (172, 128), (272, 64), (668, 32)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("k", [2, 3])
 def test_split_column_length_on_device(engine, shape, k):
     emul_tier.test_column_length_without_a_plan_is_split_into_row_blocks(engine, shape, k)
