@@ -39,7 +39,7 @@ NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI
          "KF1Q": "f1_rows_fwd", "KF2Q": "f2_cols_fwd", "KF2S": "f2s_cols_fwd1", "KF2SQ": "f2s_cols_fwd1",
          "KI1x1Q": "i1_cols_inv", "KI1x2Q": "i1_cols_inv", "KSpecNorm": "spec_norm", "KSpecRescale": "spec_rescale",
          "KDeltaNorms": "delta_norms", "KAddition": "addition_merge", "KSerialNorm": "serial_norm",
-         "KDftp": "dft_across_slices", "KDftpPairs": "dft_across_slices", "KTranspose": "transpose",
+         "KDftp": "dft_across_slices", "KDftpPairs": "dft_across_slices", "KTranspose": "transpose", "KPair1d": "pair_1d",
          "KSelect2": "select_lvl2", "KSelect2Cull": "select_lvl2_cull", "KBlendSel": "blend", "KSpecCheck": "select_spec_check", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
 
 
