@@ -261,6 +261,47 @@ def test_unsupported_lengths_fail_before_any_layer_is_merged(tmp_path, emul):
     assert not list((tmp_path / "merged").glob("*.safetensors"))          # nothing was written
 
 
+def test_cli_merges_block_tensors_whose_lengths_have_no_plan(tmp_path, emul):
+    """The pre-flight accepts, and `merge CONFIG` merges, a [86 x 64] tensor (86 = 43 * 2: split column
+    length) and a [64 x 86] one (rough row length: merged transposed) - the shapes of a Llama-2-7B MLP in
+    miniature - and the results are the oracle's."""
+    from shardmerge_amd.__main__ import cli
+    from oracle import spectral_oracle as so
+    cfg_path = gi.write_cli_model(tmp_path)
+    cfg = MergeConfig.from_yaml(cfg_path)
+    victims = {"model.layers.0.self_attn.q_proj.weight": (86, 64), "model.layers.1.self_attn.q_proj.weight": (64, 86)}
+    g = torch.Generator().manual_seed(11)
+    made = {}
+    for name, shape in victims.items():
+        base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+        made[name] = [base] + [(base.float() + torch.randn(shape, generator=g) * s_).to(torch.bfloat16) for s_ in (0.002, 0.003)]
+    for which, uri in enumerate(["org/base", "org/ft1", "org/ft2"]):
+        d = cfg.storage_path / uri
+        wm = json.load(open(d / "model.safetensors.index.json"))["weight_map"]
+        for shard in sorted({wm[v] for v in victims}):
+            with safe_open(str(d / shard), framework="pt") as f:
+                tens = {k: f.get_tensor(k) for k in f.keys()}
+            for v in victims:
+                if wm[v] == shard:
+                    tens[v] = made[v][which]
+            save_file(tens, str(d / shard), metadata={"format": "pt"})
+    res = CliRunner().invoke(cli, ["merge", str(cfg_path), "--cache-dir", str(tmp_path / "cache")])
+    assert res.exit_code == 0, res.output
+    out_dir = tmp_path / "merged"
+    wm = json.load(open(out_dir / "model.safetensors.index.json"))["weight_map"]
+    alphas = [m.alpha for m in cfg.finetune_merge]
+    for name, shape in victims.items():
+        with safe_open(str(out_dir / wm[name]), framework="pt") as f:
+            got = f.get_tensor(name)
+        base, ft1, ft2 = made[name]
+        errs = []
+        for flip in ((False, True) if shape[1] == 86 else (False,)):      # transposed merge: either orientation (DESIGN 3)
+            tt = (lambda x: x.T.contiguous()) if flip else (lambda x: x)
+            ref = so.merge_layer([tt(ft1), tt(ft2)], [tt(base)] * 2, alphas, tt(base))
+            errs.append(so.rel_err(tt(got).float(), ref.float()))
+        assert got.shape == shape and got.dtype == torch.bfloat16 and min(errs) < 2e-3, (name, errs)
+
+
 # ---- N3 / N4: operator choice and b through the YAML ------------------------------------------------
 def test_merge_options_operator_and_b(tmp_path):
     doc = {"output_base_model": "o/b", "finetune_merge": [{"model": "o/f", "base": "o/b"}], "output_dir": "out"}
