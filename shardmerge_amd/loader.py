@@ -67,6 +67,7 @@ class ShardFile:
 
 class PrefetchLoader:
     def __init__(self, index, device: str, depth: int = 2):
+        depth = int(os.environ.get("SHARDMERGE_PREFETCH_DEPTH", depth))          # layers in flight
         self.index = index
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
@@ -83,7 +84,8 @@ class PrefetchLoader:
         self.stop = False
         self.cursor = 0                # layer the consumer is at
         self.bytes_read = 0
-        self.pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="shardmerge-read")
+        self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SHARDMERGE_READ_THREADS", "4")),
+                                       thread_name_prefix="shardmerge-read")
 
     # ---- producer ---------------------------------------------------------------------
     def start(self, schedule: Sequence[Sequence[Request]]):
