@@ -3543,6 +3543,8 @@ struct DftpParams {
     int ncols;             // valid bin columns
     size_t slice_stride;   // cf4 between slices
     int inverse;
+    int cols;              // k_dftp_pairs: bin columns per work-group (16 ... 128; the fewer outputs per column - small p -
+                           // the more columns share a work-group)
 };
 SM_HD cf2 cmul(cf2 a, cf2 b) { cf2 r = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; return r; }
 template <class Ex>
@@ -3625,16 +3627,23 @@ SM_HD void k_dftp(Ex& ex, const DftpParams& p) {
 // Wh[s][h] = W_p^(s h) sits in LDS, filled once per work-group, which then walks DFTP_UNITS row units.
 constexpr int DFTP_PAIR_MAX_P = 126;
 constexpr int DFTP_UNITS = 4;
+SM_HD int dftp_pairs_cols(int p) {                 // columns per 256-thread work-group
+    const int H = p / 2 + 1;
+    if (H > 8) return DFTP_COLS;
+    int h2 = 1;
+    while (h2 < H) h2 *= 2;
+    return 256 / h2 > 128 ? 128 : 256 / h2;
+}
 SM_HD size_t dftp_pairs_lds_bytes(int p) {
     const int H = p / 2 + 1;
-    return (size_t)p * DFTP_COLS * sizeof(cf4) + (size_t)p * H * sizeof(cf2);
+    return (size_t)p * dftp_pairs_cols(p) * sizeof(cf4) + (size_t)p * H * sizeof(cf2);
 }
 template <int NP, class Ex, class St>
 SM_HD void dftp_pairs_compute(Ex& ex, St& st, const DftpParams& p, const cf4* tile, const cf2* wh, int H, int c0,
                               size_t row_off, int n1a, int n1b) {
     const int nt = ex.nthreads();
     ex.each(st, [&](int tid, EmptyState&) {
-        const int cl = tid % DFTP_COLS, hl = tid / DFTP_COLS, hstep = nt / DFTP_COLS;
+        const int cl = tid % p.cols, hl = tid / p.cols, hstep = nt / p.cols;
         const int c = c0 + cl;
         if (c >= p.ncols) return;
         vf2 A[NP], B[NP], C[NP], D[NP];
@@ -3650,7 +3659,7 @@ SM_HD void dftp_pairs_compute(Ex& ex, St& st, const DftpParams& p, const cf4* ti
                 const cf2 w = wq[j * hstep];
                 A[j] += vr * w.x; B[j] += vi * w.y; C[j] += vr * w.y; D[j] += vi * w.x;
             }
-            tp += DFTP_COLS; wq += H;
+            tp += p.cols; wq += H;
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -3676,10 +3685,11 @@ SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
     ex.init(st);
     const int nt = ex.nthreads();
     const int H = p.p / 2 + 1;
-    cf4* tile = (cf4*)(ex.lds() + LDS_SCRATCH_FLOATS);             // [p][DFTP_COLS]
-    cf2* wh = (cf2*)(tile + (size_t)p.p * DFTP_COLS);               // [p][H] (+ slack: the launch adds a row)
-    const int ntiles = (p.ncols + DFTP_COLS - 1) / DFTP_COLS;
-    const int ug = ex.bid() / ntiles, c0 = (ex.bid() % ntiles) * DFTP_COLS;
+    const int cols = p.cols;
+    cf4* tile = (cf4*)(ex.lds() + LDS_SCRATCH_FLOATS);             // [p][cols]
+    cf2* wh = (cf2*)(tile + (size_t)p.p * cols);                    // [p][H] (+ slack: the launch adds a row)
+    const int ntiles = (p.ncols + cols - 1) / cols;
+    const int ug = ex.bid() / ntiles, c0 = (ex.bid() % ntiles) * cols;
     const float sgn_im = p.inverse ? -1.f : 1.f;
     ex.each(st, [&](int tid, EmptyState&) {
         for (int idx = tid; idx < p.p * H; idx += nt) {
@@ -3688,7 +3698,7 @@ SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
             w.y *= sgn_im;
             wh[idx] = w;
         }
-        for (int idx = p.p * H + tid; idx < (p.p + 1) * H + 4 * (nt / DFTP_COLS); idx += nt) { cf2 z = {0.f, 0.f}; wh[idx] = z; }
+        for (int idx = p.p * H + tid; idx < (p.p + 1) * H + 64; idx += nt) { cf2 z = {0.f, 0.f}; wh[idx] = z; }
     });
     for (int uu = 0; uu < DFTP_UNITS; ++uu) {
         const int u = ug * DFTP_UNITS + uu;
@@ -3697,8 +3707,8 @@ SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
         const size_t row_off = ((size_t)(u / p.ilv) * p.pitch) * p.ilv + u % p.ilv;
         ex.sync();                                   // the previous unit's tile has been consumed (and wh is filled)
         ex.each(st, [&](int tid, EmptyState&) {
-            for (int idx = tid; idx < p.p * DFTP_COLS; idx += nt) {
-                const int sidx = idx / DFTP_COLS, c = c0 + idx % DFTP_COLS;
+            for (int idx = tid; idx < p.p * cols; idx += nt) {
+                const int sidx = idx / cols, c = c0 + idx % cols;
                 cf4 v = {0.f, 0.f, 0.f, 0.f};
                 if (c < p.ncols) {
                     v = p.buf[(size_t)sidx * p.slice_stride + row_off + (size_t)c * p.ilv];
@@ -3713,7 +3723,7 @@ SM_HD void k_dftp_pairs(Ex& ex, const DftpParams& p) {
             }
         });
         ex.sync();
-        const int np = (H + nt / DFTP_COLS - 1) / (nt / DFTP_COLS);
+        const int np = (H + nt / cols - 1) / (nt / cols);
         if (np <= 1) dftp_pairs_compute<1>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
         else if (np == 2) dftp_pairs_compute<2>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);
         else if (np == 3) dftp_pairs_compute<3>(ex, st, p, tile, wh, H, c0, row_off, n1a, n1b);

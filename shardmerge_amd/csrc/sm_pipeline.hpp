@@ -528,13 +528,16 @@ class Pipeline {
         if (rc) return rc;
         q.buf = (cf4*)buf; q.p = g.rough; q.M = g.R; q.units = rowpair ? g.R / 2 : g.R; q.rowpair = rowpair ? 1 : 0;
         q.ilv = ilv; q.pitch = pitch; q.ncols = g.C / 2 + 1; q.slice_stride = slice_stride; q.inverse = inverse ? 1 : 0;
-        const int ntiles = (q.ncols + DFTP_COLS - 1) / DFTP_COLS;
+        q.cols = DFTP_COLS;
         if (q.p <= DFTP_PAIR_MAX_P && dftp_pairs_enabled) {
+            q.cols = dftp_pairs_cols(q.p);
+            const int ntp = (q.ncols + q.cols - 1) / q.cols;
             // (+ one zero row of Wh and 4 * 16 entries: the unrolled units past H read there)
             const size_t ldsp = LDS_SCRATCH_FLOATS * 4 + dftp_pairs_lds_bytes(q.p) + ((size_t)(q.p / 2 + 1) + 64) * sizeof(cf2);
-            be.template launch<KDftpPairs>((q.units + DFTP_UNITS - 1) / DFTP_UNITS * ntiles, 256, ldsp, q, stream);
+            be.template launch<KDftpPairs>((q.units + DFTP_UNITS - 1) / DFTP_UNITS * ntp, 256, ldsp, q, stream);
             return SMHIP_OK;
         }
+        const int ntiles = (q.ncols + DFTP_COLS - 1) / DFTP_COLS;
         const size_t lds = LDS_SCRATCH_FLOATS * 4 + (size_t)q.p * DFTP_COLS * sizeof(cf4) + (size_t)q.p * sizeof(cf2);
         be.template launch<KDftp>(q.units * ntiles, 256, lds, q, stream);
         return SMHIP_OK;
