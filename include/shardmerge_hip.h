@@ -162,6 +162,15 @@ int smhip_addition_merge(smhip_ctx* ctx, int k, const void* const* finetunes, co
 int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int dtype, size_t rows, size_t cols,
                           float* matrix_out, void* stream);
 
+/* ---- torch.norm(x - base) as ATen's CPU kernel returns it for a contiguous fp32 tensor (the reference's
+ *      device="cpu" norms: shard/tensor/functions.py:36,40,85, shard/merge/fast_fourier.py:152,209-210):
+ *      squares rounded to fp32, accumulated serially in 8 fp32 lanes, lanes added in order, the n % 8 tail,
+ *      sqrt - reproduced bit for bit by a parallel algorithm (csrc/sm_aten_norm.hpp).  x, base (may be
+ *      NULL): device, `dtype`, n elements, 16-byte aligned.  norm_out: HOST float.  This is what
+ *      smhip_layer_desc::norm_mode = 1 uses for every spatial norm. -------------------------------- */
+int smhip_reference_cpu_norm(smhip_ctx* ctx, const void* x, const void* base, int dtype, size_t n, float* norm_out,
+                             void* stream);
+
 /* ---- test hooks: "cand_cap" clamps the capacity of the selection passes' candidate
  *      lists (0 = default) so that the overflow fallback can be exercised;
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
@@ -178,7 +187,10 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
  *      (inverse transform to fp32, forward again) as round 1 of this library did, instead of
  *      keeping it in the spectral domain (default 1). ----------------------------------- */
 int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
-/* test hook, read side: "spec_hit" = 1 if the last speculative blend's guess was confirmed, 0 if it was voided */
+/* test hook, read side: "spec_hit" = 1 if the last speculative blend's guess was confirmed, 0 if it was voided;
+ * "aten_fast" / "aten_group" / "aten_slow": chunks the last smhip_reference_cpu_norm composed from their summaries /
+ * crossed with the group summaries / walked cooperatively
+ * ("aten_serial" = 1 as an option selects the old serial single-work-group chain instead) */
 int smhip_debug_query(smhip_ctx* ctx, const char* key, long* value);
 
 /* ---- profiling: per-kernel device time measured with HIP events on the

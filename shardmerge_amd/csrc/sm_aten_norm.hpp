@@ -1,0 +1,779 @@
+// sm_aten_norm.hpp - norm_mode = reference_cpu: ||x||_2 exactly as torch.norm computes it on CPU,
+// in parallel.
+//
+// What the reference computes (torch.norm / Tensor.norm / F.normalize on a contiguous fp32 CPU
+// tensor; reference call sites shard/tensor/functions.py:36,40,85 and shard/merge/fast_fourier.py:
+// 152,209-210): ATen's vectorised L2 kernel accumulates SERIALLY in 8 fp32 lanes, acc = fma(x, x, acc)
+// (element i goes to lane i % 8; one rounding per element: on bf16-derived deltas, whose squares are
+// exact in fp32, a rounded product gives the same bits, on general fp32 data - the intermediates of a
+// K >= 3 tournament - it does not: 6 % of random 1 K-element vectors differ), adds the lanes in order,
+// then the T = n % 8 tail elements one by one - the first 4 * (T / 4) as a rounded product and an add,
+// the rest as fma: what GCC made of the scalar loop in torch 2.10's AVX2 kernel, established on
+// 510 random vectors (tools/aten_norm_model_check.py) - and takes the square root.  Once a lane's running sum S is large the adds lose low bits:
+// -7e-4 at 16 M elements, -5e-3 at 67 M (oracle/norm_bias_probe.py), and the reference's
+// pick-the-larger decisions follow the BIASED norms.
+//
+// The chain is sequential, but only formally.  While S stays inside one binade [2^e, 2^(e+1)) its
+// ulp u = 2^(e-23) is fixed and, with m = S / u (an integer),
+//     fl(S + y)  =  (m + rne(y / u)) * u        y = x^2 exactly; round to nearest, ties to EVEN m
+// so an element acts on m as   m -> m + r               (y / u not half-way: r = rne(y / u))
+//                          or  m -> m + q + ((m + q) & 1)   (y / u = q + 1/2: tie, result even).
+// Both are maps of the form  f(m) = m + A + B[m & 1]  (A common, B[0], B[1] the tie round-ups for an
+// even / odd start), and such maps are CLOSED under composition:
+//     (g o f):  A = Af + Ag,  B[p] = Bf[p] + Bg[(p + Af + Bf[p]) & 1].
+// A run of elements that stays inside one binade is therefore summarised EXACTLY, ties included,
+// by three numbers that can be computed for disjoint pieces in parallel and composed in order.
+// Only the ~log2(n) binade crossings per lane are walked serially.
+//
+//   k_aten_pre    per chunk (8192 rows of 8) and lane: the sum of the squares, estimated from a 1-in-16
+//                 sample - used only to PREDICT the binade S will be in around the chunk
+//   k_aten_scan   inclusive prefix of those sums per lane
+//   k_aten_part   per chunk and lane: the summary (A, B0, B1) for the binade of the prefix at the chunk's
+//                 end and for the one below it (S trails the exact sum by its bias), for the whole
+//                 chunk and for its 32 groups of 256 rows; the data goes through LDS so that loads are
+//                 coalesced while every thread summarises consecutive rows
+//   k_aten_walk   one work-group per (signal, lane): composes chunk summaries while S stays in the
+//                 binade they were made for.  A chunk in which S moves up a binade: its group summaries
+//                 locate the 256 rows that hold the crossing, one thread adds those with real fp32
+//                 fmas, the groups behind are composed in the new binade.  Anything else (the first
+//                 chunks, where S crosses a binade every few elements; a prediction that was off) is
+//                 redone cooperatively from the data - thread summaries for the actual binade, serial
+//                 adds in the thread where it ends, again
+//   k_aten_finish lanes added in order, the tail, sqrt
+//
+// Bit-identical to torch.norm for every input (tests: emulator tier and on the device), whatever
+// the predictions were: a wrong prediction only sends a chunk through the cooperative path.
+//
+// The same machinery takes the norms of the gathered slerp-class vectors (functions.py:36,40) on
+// the spectrum planes (AtenSrc kind 1).  There bit-identity is not on offer - the reference gathers
+// in the row-major order of ITS full spectrum, whose values differ from ours in the last bits - but
+// the bias is a statistical property of the values: emulating the sum over our planes (a bin that
+// stands for itself and its conjugate twin is added twice, bins outside the class add an exact
+// zero) reproduces the reference's norms to 2e-6 where exact norms are off by 2e-4 (4096^2;
+// tools/aten_norm_model_check.py).
+#pragma once
+#include "sm_kernels.hpp"
+
+namespace smhip {
+
+constexpr int ATEN_LANES = 8;                  // Vectorized<float>::size() of ATen's AVX2 build
+constexpr int ATEN_THREADS = 256;
+constexpr int ATEN_ROWS_PER_THREAD = 32;       // rows of 8 elements per thread
+constexpr int ATEN_CHUNK_ROWS = ATEN_THREADS * ATEN_ROWS_PER_THREAD;      // 8192 rows = 65536 elements
+constexpr int ATEN_MAX_SIGS = 16;
+constexpr int ATEN_NO_EXP = -32768;
+
+// a stream of rows of 8 values
+struct AtenSrc {
+    int kind;                   // 0: a signal (x - base) of n elements; 1: the slerp class of two spectrum planes
+    SigDesc sig;                // kind 0
+    const float* reA;           // kind 1: planes [Cb][R]
+    const float* reB;
+    const float* thr;           // device scalar (cutoff threshold) or null (-> 0)
+    int which;                  // kind 1: 0 = the class's Re a values (v0), 1 = its Re b values (v1)
+    int R, C, Cb;               // kind 1: bin multiplicities (weight_ranges)
+    size_t n;                   // elements (kind 0) / plane elements (kind 1)
+};
+SM_HD size_t aten_rows(const AtenSrc& s) { return s.kind == 0 ? s.n / 8 : (s.n + 7) / 8; }
+
+SM_HD float aten_sq(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmul_rn(v, v);
+#else
+    volatile float r = v * v;
+    return r;
+#endif
+}
+SM_HD float aten_fma(float x, float s) {        // fl(x * x + s), one rounding
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmaf_rn(x, x, s);
+#else
+    return std::fmaf(x, x, s);
+#endif
+}
+SM_HD float aten_fadd(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fadd_rn(a, b);                    // never contracted with the multiply that made b
+#else
+    volatile float r = a + b;
+    return r;
+#endif
+}
+
+// "counts twice" bits of the 8 plane elements from i0 on: one modulo per row at most, and no per-element test
+// unless the row straddles the edge of a self-conjugate column
+SM_HD uint32_t aten_row_w2(const WeightRanges& w, size_t i0) {
+    if (w.full) return 0u;
+    if (w.period) i0 %= w.period;
+    const size_t i1 = i0 + 8;
+    const bool in0 = i1 <= w.hi0, inN = i0 >= w.loN && i1 <= w.hiN;
+    if (in0 || inN) return 0u;
+    const bool clear = i0 >= w.hi0 && (i1 <= w.loN || i0 >= w.hiN) && (!w.period || i1 <= w.period);
+    if (clear) return 0xffu;
+    uint32_t m = 0u;
+    for (int e = 0; e < 8; ++e) {
+        size_t i = i0 + e;
+        if (w.period && i >= w.period) i -= w.period;
+        if (!(i < w.hi0 || (i >= w.loN && i < w.hiN))) m |= 1u << e;
+    }
+    return m;
+}
+// row r: the 8 values y[] (zero outside the class), bit l of the return value set when element l counts twice
+template <int KIND>
+SM_HD uint32_t aten_load_row(const AtenSrc& s, const WeightRanges& wr, float thr, size_t r, float* y) {
+    if (KIND == 0) {
+        load_sig8(s.sig, r * 8, y);
+        return 0u;
+    }
+    const size_t i0 = r * 8;
+    if (i0 + 8 <= s.n) {
+        const cf4 a0 = ((const cf4*)s.reA)[i0 / 4], a1 = ((const cf4*)s.reA)[i0 / 4 + 1];
+        const cf4 b0 = ((const cf4*)s.reB)[i0 / 4], b1 = ((const cf4*)s.reB)[i0 / 4 + 1];
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool in = same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr);
+            const float v = s.which ? b[e] : a[e];
+            y[e] = in ? v : 0.f;
+        }
+        return aten_row_w2(wr, i0);
+    }
+    uint32_t w2 = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        y[e] = 0.f;
+        if (i0 + e < s.n) {
+            const float a = s.reA[i0 + e], b = s.reB[i0 + e];
+            const bool in = same_sign(a, b) && !(fabsf(b) < thr);
+            const float v = s.which ? b : a;
+            y[e] = in ? v : 0.f;
+            if (weight_at(wr, i0 + e) == 2u) w2 |= 1u << e;
+        }
+    }
+    return w2;
+}
+// one lane's element of row r; twice = it counts twice
+template <int KIND>
+SM_HD float aten_load_one(const AtenSrc& s, const WeightRanges& wr, float thr, size_t r, int lane, bool& twice) {
+    const size_t i = r * 8 + lane;
+    twice = false;
+    if (KIND == 0) return load_sig1(s.sig, i);
+    if (i >= s.n) return 0.f;
+    const float a = s.reA[i], b = s.reB[i];
+    const bool in = same_sign(a, b) && !(fabsf(b) < thr);
+    if (!in) return 0.f;
+    twice = weight_at(wr, i) == 2u;
+    return s.which ? b : a;
+}
+
+// running summary of a thread's elements (at most 64 additions) for one exponent.  A stays below 2^31: one
+// element contributes at most 2^25 - from 2^24 on the sum has left the binade and the summary is void anyway
+struct AtenAcc { uint32_t A, B0, B1; };
+SM_HD void aten_acc_zero(AtenAcc& s) { s.A = 0u; s.B0 = 0u; s.B1 = 0u; }
+constexpr double ATEN_UNIT_CLAMP = 33554432.0;
+// scale = 2^(23 - e): x^2 * scale is the (exact) square in units of the binade's ulp
+SM_HD void aten_acc_add(AtenAcc& s, float x, double scale) {
+    double v = (double)x * (double)x * scale;
+    v = v < ATEN_UNIT_CLAMP ? v : ATEN_UNIT_CLAMP;  // (NaN / Inf land here too: the summary is void and the serial adds
+                                                    // produce the NaN / Inf)
+    const double fl = floor(v);
+    const double fr = v - fl;
+    const uint32_t q = (uint32_t)(int)fl;
+    const uint32_t up = fr > 0.5 ? 1u : 0u, tie = fr == 0.5 ? 1u : 0u;
+    s.A += q + up;
+    // tie: m + q odd -> rounds up to the even neighbour (m = start + A + B[start & 1])
+    s.B0 += tie & (s.A ^ s.B0) & 1u;
+    s.B1 += tie & (1u ^ s.A ^ s.B1) & 1u;
+}
+// f(m) = m + A + (m & 1 ? B1 : B0); pA = A & 1 rides in bit 31 of B1p; A = +inf: no summary ("stop")
+struct AtenSum { double A; uint32_t B0, B1p; };
+SM_HD AtenSum aten_sum_identity() { AtenSum r; r.A = 0.0; r.B0 = 0u; r.B1p = 0u; return r; }
+SM_HD AtenSum aten_sum_stop() { AtenSum r; r.A = INFINITY; r.B0 = 0u; r.B1p = 0u; return r; }
+SM_HD AtenSum aten_sum_of(const AtenAcc& a) {
+    AtenSum r; r.A = (double)a.A; r.B0 = a.B0; r.B1p = (a.B1 & 0x7fffffffu) | ((a.A & 1u) << 31); return r;
+}
+SM_HD AtenSum aten_compose(const AtenSum& l, const AtenSum& r) {      // l first, then r
+    const uint32_t pl = l.B1p >> 31, lb1 = l.B1p & 0x7fffffffu;
+    const uint32_t pr = r.B1p >> 31, rb1 = r.B1p & 0x7fffffffu;
+    const uint32_t mid0 = (pl ^ l.B0) & 1u, mid1 = (1u ^ pl ^ lb1) & 1u;
+    AtenSum o;
+    o.A = l.A + r.A;
+    o.B0 = l.B0 + (mid0 ? rb1 : r.B0);
+    const uint32_t b1 = lb1 + (mid1 ? rb1 : r.B0);
+    o.B1p = (b1 & 0x7fffffffu) | ((pl ^ pr) << 31);
+    return o;
+}
+SM_HD double aten_apply(double m, uint32_t odd, const AtenSum& f) {
+    return m + f.A + (double)(odd ? (f.B1p & 0x7fffffffu) : f.B0);
+}
+SM_HD double aten_pow2(int e) {                 // 2^e as a double, -1022 <= e <= 1023
+    const unsigned long long b = (unsigned long long)(1023 + e) << 52;
+    double d; memcpy(&d, &b, 8); return d;
+}
+// S normal and not tiny: its binade e, its mantissa m (2^23 <= m < 2^24)
+SM_HD bool aten_split(float S, int& e, uint32_t& m) {
+    const uint32_t b = f2u(S);
+    const int ex = (int)((b >> 23) & 0xffu);
+    if ((b >> 31) || ex == 0 || ex == 255) return false;      // negative / zero, denormal / Inf, NaN
+    e = ex - 127; m = (b & 0x7fffffu) | 0x800000u;
+    return true;
+}
+SM_HD float aten_join(int e, double m) {        // m * 2^(e-23), m an integer <= 2^24: exact
+    return (float)(m * aten_pow2(e - 23));
+}
+
+// ---- k_aten_pre: per-chunk lane sums, ESTIMATED from a sample --------------------------------------
+// The sums only predict the binade a chunk will be met in (a wrong prediction costs time, never the
+// result), so one piece of 8 rows in every ATEN_SAMPLE is read: 6 % of the data.
+constexpr int ATEN_SAMPLE = 16;
+struct AtenPreParams {
+    int nsig;
+    AtenSrc src[ATEN_MAX_SIGS];
+    size_t nchunks;             // of the longest signal (a shorter signal's chunks past its end are zero)
+    double* pre;                // [nsig][nchunks][8]
+};
+template <int KIND, class Ex>
+SM_HD void k_aten_pre(Ex& ex, const AtenPreParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int sig = ex.bid() % p.nsig;
+    const size_t chunk = (size_t)(ex.bid() / p.nsig);
+    const AtenSrc& s = p.src[sig];
+    const size_t rows = aten_rows(s);
+    const WeightRanges wr = weight_ranges(s.R, s.C, s.Cb);
+    const float thr = (KIND == 1 && s.thr) ? *s.thr : 0.f;
+    ex.each(st, [&](int tid, EmptyState& q) {
+        double acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = 0.0;
+        constexpr int PER = ATEN_CHUNK_ROWS / ATEN_SAMPLE / ATEN_THREADS;      // sampled rows per thread (2)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * ATEN_THREADS + tid;                               // sampled row: piece j / 8, row j % 8 of it
+            const size_t r = chunk * ATEN_CHUNK_ROWS + (size_t)(j / 8) * (8 * ATEN_SAMPLE) + (j % 8);
+            if (r < rows) {
+                float y[8];
+                const uint32_t w2 = aten_load_row<KIND>(s, wr, thr, r, y);
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] += (double)y[l] * (double)y[l] * (((w2 >> l) & 1u) ? 2.0 : 1.0);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) q.red[l] = acc[l] * (double)ATEN_SAMPLE;
+    });
+    ex.template block_sum<8>(st, [&](const double* tot) {
+        double* o = p.pre + ((size_t)sig * p.nchunks + chunk) * 8;
+        for (int l = 0; l < 8; ++l) o[l] = tot[l];
+    });
+}
+
+// ---- k_aten_scan: INCLUSIVE prefix per (signal, lane), in place --------------------------------
+struct AtenScanParams { double* pre; size_t nchunks; };
+template <class Ex>
+SM_HD void k_aten_scan(Ex& ex, const AtenScanParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    double* blk = (double*)(ex.lds() + LDS_SCRATCH_FLOATS);        // [32][8] block totals
+    double* base = p.pre + (size_t)ex.bid() * p.nchunks * 8;
+    const size_t per = (p.nchunks + 31) / 32;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const int lane = tid & 7, b = tid >> 3;
+        double sum = 0.0;
+        for (size_t c = (size_t)b * per; c < (size_t)(b + 1) * per && c < p.nchunks; ++c) sum += base[c * 8 + lane];
+        blk[b * 8 + lane] = sum;
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const int lane = tid & 7, b = tid >> 3;
+        double run = 0.0;
+        for (int q = 0; q < b; ++q) run += blk[q * 8 + lane];
+        for (size_t c = (size_t)b * per; c < (size_t)(b + 1) * per && c < p.nchunks; ++c) {
+            run += base[c * 8 + lane];
+            base[c * 8 + lane] = run;
+        }
+    });
+}
+
+// ---- k_aten_part: chunk summaries for the predicted exponent and the one below -----------------
+struct AtenPartParams {
+    int nsig;
+    AtenSrc src[ATEN_MAX_SIGS];
+    size_t nchunks;
+    const double* prefix;       // [nsig][nchunks][8]: (estimated) sum of the lane's squares up to the END of the chunk:
+                                // the running sum trails it slightly, so it meets the chunk in that binade or the one
+                                // below - and a chunk in which it moves up a binade has summaries for both
+    AtenSum* rec;               // [nsig][nchunks][8][2]
+    AtenSum* grp;               // [nsig][nchunks][8][2][32]: the same per group of 256 rows (8 threads)
+    int* epred;                 // [nsig][nchunks][8]
+};
+constexpr int ATEN_GROUPS = 32;                 // groups of 8 threads = 256 rows per chunk
+constexpr int ATEN_GROUP_ROWS = ATEN_CHUNK_ROWS / ATEN_GROUPS;
+SM_HD int aten_exp_of(double v) {               // floor(log2 v) for a normal v > 0, else ATEN_NO_EXP
+    unsigned long long b; memcpy(&b, &v, 8);
+    const int ex = (int)((b >> 52) & 0x7ffu);
+    if ((b >> 63) || ex == 0 || ex == 0x7ff) return ATEN_NO_EXP;
+    const int e = ex - 1023;
+    return (e < -100 || e > 127) ? ATEN_NO_EXP : e;
+}
+// both candidates from one multiply: `fine` works in the ulp of binade e - 1 (scale_fine = 2^(24 - e)),
+// `coarse` in that of binade e.  y / u_coarse = (q1 + fr1) / 2 with q1 = floor(y / u_fine):
+// above half-way <=> q1 odd and fr1 > 0, half-way <=> q1 odd and fr1 == 0.
+SM_HD void aten_acc_add2(AtenAcc& coarse, AtenAcc& fine, float x, double scale_fine) {
+    double v = (double)x * (double)x * scale_fine;
+    v = v < ATEN_UNIT_CLAMP ? v : ATEN_UNIT_CLAMP;
+    const double fl = floor(v);
+    const double fr = v - fl;
+    const uint32_t q1 = (uint32_t)(int)fl;
+    {
+        const uint32_t up = fr > 0.5 ? 1u : 0u, tie = fr == 0.5 ? 1u : 0u;
+        fine.A += q1 + up;
+        fine.B0 += tie & (fine.A ^ fine.B0) & 1u;
+        fine.B1 += tie & (1u ^ fine.A ^ fine.B1) & 1u;
+    }
+    {
+        const uint32_t odd = q1 & 1u, q0 = q1 >> 1;
+        const uint32_t up = odd & (fr > 0.0 ? 1u : 0u), tie = odd & (fr == 0.0 ? 1u : 0u);
+        coarse.A += q0 + up;
+        coarse.B0 += tie & (coarse.A ^ coarse.B0) & 1u;
+        coarse.B1 += tie & (1u ^ coarse.A ^ coarse.B1) & 1u;
+    }
+}
+// The chunk goes through LDS in ATEN_STAGES stages of 8 rows per thread: the loads are coalesced (8
+// consecutive threads fetch 8 consecutive rows), each thread then reads ITS 8 rows back - a thread's
+// rows must be consecutive for its summary to mean anything.
+constexpr double ATEN_LAG_MARGIN = 0.2;         // how far below the exact prefix the running sum is allowed for
+constexpr int ATEN_STAGE_ROWS = 8;
+constexpr int ATEN_STAGES = ATEN_ROWS_PER_THREAD / ATEN_STAGE_ROWS;
+constexpr int ATEN_STAGE_PITCH = ATEN_STAGE_ROWS * 8 + 4;          // floats per thread: 256 B + 16 B (bank spread)
+constexpr size_t ATEN_PART_LDS_FLOATS = (size_t)ATEN_THREADS * ATEN_STAGE_PITCH + ATEN_THREADS * ATEN_STAGE_ROWS / 4 + 64;
+struct AtenPartState { AtenAcc a[16]; AtenSum s[16]; double red[8]; };
+template <int KIND, class Ex>
+SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
+    typename Ex::template State<AtenPartState> st;
+    ex.init(st);
+    const int sig = ex.bid() % p.nsig;
+    const size_t chunk = (size_t)(ex.bid() / p.nsig);
+    const AtenSrc& s = p.src[sig];
+    const size_t rows = aten_rows(s);
+    const WeightRanges wr = weight_ranges(s.R, s.C, s.Cb);
+    const float thr = (KIND == 1 && s.thr) ? *s.thr : 0.f;
+    float* stage = ex.lds() + LDS_SCRATCH_FLOATS;                   // [256 threads][8 rows][8] (+ pad)
+    uint8_t* w2row = (uint8_t*)(stage + (size_t)ATEN_THREADS * ATEN_STAGE_PITCH);      // [2048]: a row's "counts twice" bits
+    AtenSum* ent = (AtenSum*)stage;                                 // after the stages: [8 lanes][256 threads]
+    AtenSum* seg = ent + 8 * ATEN_THREADS;                          // [8 lanes][32 groups]
+    const size_t slot = ((size_t)sig * p.nchunks + chunk) * 8;
+    // a lane whose sum cannot be a binade below the prediction anywhere in the chunk (the prefix at the chunk's
+    // START, less a margin for the sum's bias and the sampling error, is already in it) gets one summary only
+    int ep[8];
+    uint32_t two = 0u;
+    for (int l = 0; l < 8; ++l) {
+        ep[l] = aten_exp_of(p.prefix[slot + l]);
+        const double before = chunk > 0 ? p.prefix[slot - 8 + l] : 0.0;
+        if (ep[l] == ATEN_NO_EXP || aten_exp_of(before * (1.0 - ATEN_LAG_MARGIN)) != ep[l]) two |= 1u << l;
+    }
+    ex.each(st, [&](int, AtenPartState& q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aten_acc_zero(q.a[i]);         // [lane][cand]: cand 0 = ep, cand 1 = ep - 1
+    });
+    const size_t row0 = chunk * ATEN_CHUNK_ROWS;
+    for (int sidx = 0; sidx < ATEN_STAGES; ++sidx) {
+        if (row0 + (size_t)sidx * ATEN_STAGE_ROWS >= rows) break;   // (uniform) nothing left: thread 0's rows are past the end
+        ex.each(st, [&](int tid, AtenPartState&) {
+#pragma unroll
+            for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
+                const int q = i * ATEN_THREADS + tid;                       // row of the stage: owner q / 8, its row q % 8
+                const size_t r = row0 + (size_t)(q / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (q % 8);
+                float y[8];
+                uint32_t w2 = 0u;
+                if (r < rows) w2 = aten_load_row<KIND>(s, wr, thr, r, y);
+                else { for (int e = 0; e < 8; ++e) y[e] = 0.f; }
+                float* d = stage + (size_t)(q / 8) * ATEN_STAGE_PITCH + (q % 8) * 8;
+                cf4 lo = {y[0], y[1], y[2], y[3]}, hi = {y[4], y[5], y[6], y[7]};
+                ((cf4*)d)[0] = lo; ((cf4*)d)[1] = hi;
+                if (KIND == 1) w2row[q] = (uint8_t)w2;
+            }
+        });
+        ex.sync();
+        ex.each(st, [&](int tid, AtenPartState& q) {
+            double scale[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) scale[l] = ep[l] == ATEN_NO_EXP ? 0.0 : aten_pow2(24 - ep[l]);
+            const float* src = stage + (size_t)tid * ATEN_STAGE_PITCH;
+#pragma unroll
+            for (int k = 0; k < ATEN_STAGE_ROWS; ++k) {
+                const cf4 lo = ((const cf4*)(src + k * 8))[0], hi = ((const cf4*)(src + k * 8))[1];
+                const float y[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const uint32_t w2 = KIND == 1 ? w2row[tid * 8 + k] : 0u;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int reps = ((w2 >> l) & 1u) ? 2 : 1;
+                    if ((two >> l) & 1u) { for (int r = 0; r < reps; ++r) aten_acc_add2(q.a[2 * l], q.a[2 * l + 1], y[l], scale[l]); }
+                    else { for (int r = 0; r < reps; ++r) aten_acc_add(q.a[2 * l], y[l], scale[l] * 0.5); }
+                }
+            }
+        });
+        ex.sync();
+    }
+    ex.each(st, [&](int, AtenPartState& q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q.s[i] = ((i & 1) && !((two >> (i / 2)) & 1u)) ? aten_sum_stop() : aten_sum_of(q.a[i]);
+    });
+    for (int cand = 0; cand < 2; ++cand) {
+        ex.each(st, [&](int tid, AtenPartState& q) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) ent[l * ATEN_THREADS + tid] = cand ? q.s[2 * l + 1] : q.s[2 * l];
+        });
+        ex.sync();
+        ex.each(st, [&](int tid, AtenPartState&) {                  // 8 lanes x 32 groups of 8 threads
+            const int lane = tid >> 5, g = tid & 31;
+            AtenSum run = aten_sum_identity();
+            for (int j = 0; j < 8; ++j) run = aten_compose(run, ent[lane * ATEN_THREADS + g * 8 + j]);
+            seg[lane * 32 + g] = run;
+            p.grp[((slot + lane) * 2 + cand) * ATEN_GROUPS + g] = run;
+        });
+        ex.sync();
+        ex.each(st, [&](int tid, AtenPartState&) {
+            if (tid < 8) {
+                AtenSum run = aten_sum_identity();
+                for (int g = 0; g < 32; ++g) run = aten_compose(run, seg[tid * 32 + g]);
+                p.rec[(slot + tid) * 2 + cand] = run;
+                if (cand == 0) p.epred[slot + tid] = ep[tid];
+            }
+        });
+        ex.sync();
+    }
+}
+
+// ---- k_aten_walk: one work-group per (signal, lane) -------------------------------------------
+struct AtenWalkParams {
+    int nsig;
+    AtenSrc src[ATEN_MAX_SIGS];
+    size_t nchunks;             // stride of rec / grp / epred
+    const AtenSum* rec;         // null: no summaries (small inputs): every chunk is walked cooperatively
+    const AtenSum* grp;
+    const int* epred;
+    float* lanes;               // [nsig][8]
+    uint32_t* stats;            // optional [nsig][8][4]: chunks composed / crossed by groups / walked cooperatively / -
+};
+// LDS of the walker (floats past LDS_SCRATCH_FLOATS)
+constexpr int ATEN_YPITCH = ATEN_ROWS_PER_THREAD + 1;
+constexpr int ATEN_WALK_LDS_FLOATS = ATEN_THREADS * ATEN_YPITCH + ATEN_THREADS + 4 * (2 * ATEN_THREADS + 16) + 16;
+constexpr int ATEN_SERIAL0 = 64;                // thread ranges a fresh sum is carried through serially (2048 elements)
+struct AtenCtl { float S; int t_first; double m_at; double m_end; int bad; int pad; };
+
+// entries ent[0..255] applied in order to m0 (binade e): first entry after which m >= 2^24 (or
+// that is a "stop") -> ctl.t_first (256: none), m in front of it -> ctl.m_at (= m after all of them
+// when there is none)
+template <class Ex, class StT>
+SM_HD void aten_resolve(Ex& ex, StT& st, const AtenSum* ent, AtenSum* pre, AtenSum* seg, uint32_t m0, AtenCtl* ctl) {
+    using S = typename StT::value_type;
+    ex.each(st, [&](int tid, S&) {
+        if (tid < 16) {
+            AtenSum run = aten_sum_identity();
+            for (int j = 0; j < 16; ++j) { run = aten_compose(run, ent[tid * 16 + j]); pre[tid * 16 + j] = run; }
+            seg[tid] = run;
+        }
+    });
+    ex.sync();
+    ex.each(st, [&](int tid, S&) {
+        if (tid != 0) return;
+        const double lim = 16777216.0;
+        double m = (double)m0;
+        uint32_t odd = m0 & 1u;
+        int tf = 256;
+        for (int g = 0; g < 16 && tf == 256; ++g) {
+            const double mg = aten_apply(m, odd, seg[g]);
+            if (mg < lim) { m = mg; odd = (uint32_t)((unsigned long long)mg & 1ull); continue; }
+            double prev = m;
+            for (int j = 0; j < 16; ++j) {
+                const double mj = aten_apply(m, odd, pre[g * 16 + j]);
+                if (!(mj < lim)) { tf = g * 16 + j; break; }
+                prev = mj;
+            }
+            if (tf == 256) tf = g * 16 + 15;        // (cannot happen: the segment total is its last prefix)
+            m = prev;
+        }
+        ctl->t_first = tf; ctl->m_at = m; ctl->m_end = m;
+    });
+    ex.sync();
+}
+
+template <int KIND, class Ex>
+SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int sig = ex.bid() / 8, lane = ex.bid() % 8;
+    const AtenSrc& s = p.src[sig];
+    const size_t rows = aten_rows(s);
+    const size_t nch = (rows + ATEN_CHUNK_ROWS - 1) / ATEN_CHUNK_ROWS;
+    const WeightRanges wr = weight_ranges(s.R, s.C, s.Cb);
+    const float thr = (KIND == 1 && s.thr) ? *s.thr : 0.f;
+    float* ybuf = ex.lds() + LDS_SCRATCH_FLOATS;                            // [256][33]
+    uint32_t* wbits = (uint32_t*)(ybuf + ATEN_THREADS * ATEN_YPITCH);      // [256]: bit k = element k of the thread counts twice
+    AtenSum* ent = (AtenSum*)(wbits + ATEN_THREADS);                        // [256]
+    AtenSum* pre = ent + ATEN_THREADS;                                      // [256]
+    AtenSum* seg = pre + ATEN_THREADS;                                      // [16]
+    AtenCtl* ctl = (AtenCtl*)(seg + 16);
+    ex.each(st, [&](int tid, EmptyState&) { if (tid == 0) { ctl->S = 0.f; ctl->bad = 0; ctl->t_first = 0; } });
+    ex.sync();
+    uint32_t n_fast = 0, n_group = 0, n_slow = 0;
+
+    auto set_S = [&](float v) {                     // (callers have a barrier behind their last read of ctl)
+        ex.each(st, [&](int tid, EmptyState&) {
+            if (tid == 0) { ctl->S = v; if (!(v - v == 0.f)) ctl->bad = 1; }
+        });
+        ex.sync();
+    };
+    // thread ranges [t0, t1] of the staged data (32 elements each), added serially by one thread; a range
+    // is read into registers before its chain of dependent fmas starts
+    auto serial_add = [&](float S, int t0, int t1) {
+        ex.each(st, [&](int tid, EmptyState&) {
+            if (tid != 0) return;
+            float acc = S;
+            for (int t = t0; t <= t1; ++t) {
+                float y[ATEN_ROWS_PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < ATEN_ROWS_PER_THREAD; ++k) y[k] = ybuf[t * ATEN_YPITCH + k];
+                const uint32_t wb = KIND == 1 ? wbits[t] : 0u;
+                if (wb == 0u) {
+#pragma unroll
+                    for (int k = 0; k < ATEN_ROWS_PER_THREAD; ++k) acc = aten_fma(y[k], acc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < ATEN_ROWS_PER_THREAD; ++k) {
+                        acc = aten_fma(y[k], acc);
+                        if ((wb >> k) & 1u) acc = aten_fma(y[k], acc);
+                    }
+                }
+            }
+            ctl->S = acc;
+            if (!(acc - acc == 0.f)) ctl->bad = 1;                         // Inf / NaN: nothing further changes the verdict
+        });
+        ex.sync();
+    };
+    // rows [r0, r0 + nrows) of this lane -> ybuf / wbits in thread-range order (nrows <= ATEN_CHUNK_ROWS)
+    auto stage_rows = [&](size_t r0, int nrows) {
+        if (KIND == 1) {
+            ex.each(st, [&](int tid, EmptyState&) { wbits[tid] = 0u; });
+            ex.sync();
+        }
+        ex.each(st, [&](int tid, EmptyState&) {
+            for (int j = tid; j < nrows; j += ATEN_THREADS) {               // coalesced
+                const size_t r = r0 + (size_t)j;
+                bool twice = false;
+                const float y = r < rows ? aten_load_one<KIND>(s, wr, thr, r, lane, twice) : 0.f;
+                ybuf[(j / ATEN_ROWS_PER_THREAD) * ATEN_YPITCH + (j % ATEN_ROWS_PER_THREAD)] = y;
+                if (twice) ex.lds_atomic_add(&wbits[j / ATEN_ROWS_PER_THREAD], 1u << (j % ATEN_ROWS_PER_THREAD));
+            }
+        });
+        ex.sync();
+    };
+    // chunk c from ctl->S, cooperatively: thread summaries for the binade S is in, the thread whose
+    // elements leave it adds them serially, again for the rest
+    auto walk_chunk = [&](size_t c) {
+        stage_rows(c * ATEN_CHUNK_ROWS, ATEN_CHUNK_ROWS);
+        int lo = 0;                                                         // first thread whose elements are still to come
+        while (lo < ATEN_THREADS) {
+            if (ctl->bad) break;
+            const float Sc = ctl->S;
+            int ec = 0; uint32_t mc = 0;
+            const bool nrm = aten_split(Sc, ec, mc);
+            const double scale = nrm ? aten_pow2(23 - ec) : 0.0;
+            ex.each(st, [&](int tid, EmptyState&) {
+                AtenSum v = aten_sum_identity();
+                if (tid >= lo) {
+                    const float* yy = ybuf + tid * ATEN_YPITCH;
+                    const uint32_t wb = KIND == 1 ? wbits[tid] : 0u;
+                    if (nrm) {
+                        AtenAcc acc;
+                        aten_acc_zero(acc);
+                        for (int k = 0; k < ATEN_ROWS_PER_THREAD; ++k) {
+                            const float y = yy[k];
+                            aten_acc_add(acc, y, scale);
+                            if ((wb >> k) & 1u) aten_acc_add(acc, y, scale);
+                        }
+                        v = aten_sum_of(acc);
+                    } else {
+                        // S is zero (or denormal): no binade to work in - the first thread that holds a
+                        // non-zero element starts the serial adds
+                        bool any = false;
+                        for (int k = 0; k < ATEN_ROWS_PER_THREAD; ++k) any = any || (yy[k] != 0.f);
+                        if (any) v = aten_sum_stop();
+                    }
+                }
+                ent[tid] = v;
+            });
+            ex.sync();
+            aten_resolve(ex, st, ent, pre, seg, nrm ? mc : 0x800000u, ctl);
+            const int tf = ctl->t_first;
+            const double m_at = ctl->m_at;
+            ex.sync();
+            const float Sat = nrm ? aten_join(ec, m_at) : Sc;
+            if (tf >= ATEN_THREADS) { set_S(Sat); break; }
+            // a fresh sum crosses a binade every few elements at first: carry it on serially for a while
+            int tend = tf;
+            if (!nrm && tf < ATEN_SERIAL0) tend = ATEN_SERIAL0 - 1;
+            serial_add(Sat, tf, tend);
+            lo = tend + 1;
+        }
+    };
+
+    size_t c = 0;
+    while (c < nch) {
+        if (ctl->bad) break;
+        int e = 0; uint32_t m0 = 0;
+        const float S0 = ctl->S;
+        const bool normal = aten_split(S0, e, m0);
+        if (!(normal && p.rec)) { ++n_slow; walk_chunk(c); ++c; continue; }
+        // chunks c .. c+255 whose summary was made for binade e
+        ex.each(st, [&](int tid, EmptyState&) {
+            const size_t cc = c + tid;
+            AtenSum v = aten_sum_identity();
+            if (cc < nch) {
+                const size_t slot = ((size_t)sig * p.nchunks + cc) * 8 + lane;
+                const int k = p.epred[slot] - e;
+                v = (p.epred[slot] != ATEN_NO_EXP && (k == 0 || k == 1)) ? p.rec[slot * 2 + k] : aten_sum_stop();
+            }
+            ent[tid] = v;
+        });
+        ex.sync();
+        aten_resolve(ex, st, ent, pre, seg, m0, ctl);
+        const int adv = ctl->t_first;
+        const float Snew = aten_join(e, ctl->m_at);
+        ex.sync();
+        set_S(Snew);
+        const size_t left = nch - c;
+        const size_t took = (size_t)adv < left ? (size_t)adv : left;
+        n_fast += (uint32_t)took;
+        c += took;
+        if (adv == 256 || c >= nch) continue;
+        // ---- chunk c leaves binade e (or was summarised for another one) ----------------------------
+        const size_t slot = ((size_t)sig * p.nchunks + c) * 8 + lane;
+        const int ep = p.epred[slot];
+        const int k0 = ep - e;
+        bool done = false;
+        if (ep != ATEN_NO_EXP && (k0 == 0 || k0 == 1)) {
+            // its 32 group summaries find the group of 256 rows that holds the crossing; that group is
+            // added serially, the groups behind it are composed in the binade the sum has moved to
+            uint32_t me = 0; int ee = 0;
+            aten_split(Snew, ee, me);                                       // (= e, m after the chunks composed)
+            ex.each(st, [&](int tid, EmptyState&) {
+                ent[tid] = tid < ATEN_GROUPS ? p.grp[(slot * 2 + k0) * ATEN_GROUPS + tid] : aten_sum_identity();
+            });
+            ex.sync();
+            aten_resolve(ex, st, ent, pre, seg, me, ctl);
+            const int g = ctl->t_first;
+            const float Sg = aten_join(e, ctl->m_at);
+            ex.sync();
+            if (g < ATEN_GROUPS) {
+                stage_rows(c * ATEN_CHUNK_ROWS + (size_t)g * ATEN_GROUP_ROWS, ATEN_GROUP_ROWS);
+                serial_add(Sg, 0, ATEN_GROUP_ROWS / ATEN_ROWS_PER_THREAD - 1);
+                const float S2 = ctl->S;
+                int e2 = 0; uint32_t m2 = 0;
+                const bool n2 = aten_split(S2, e2, m2);
+                const int k2 = ep - e2;
+                if (ctl->bad) { done = true; }
+                else if (n2 && (k2 == 0 || k2 == 1)) {
+                    ex.each(st, [&](int tid, EmptyState&) {
+                        ent[tid] = (tid > g && tid < ATEN_GROUPS) ? p.grp[(slot * 2 + k2) * ATEN_GROUPS + tid] : aten_sum_identity();
+                    });
+                    ex.sync();
+                    aten_resolve(ex, st, ent, pre, seg, m2, ctl);
+                    const int g2 = ctl->t_first;
+                    const float S3 = aten_join(e2, ctl->m_at);
+                    ex.sync();
+                    if (g2 >= ATEN_THREADS) { set_S(S3); done = true; ++n_group; }
+                }
+            }
+            if (!done) set_S(Snew);                                         // a second crossing (or a prediction two binades off): from the top
+        }
+        if (!done) { ++n_slow; walk_chunk(c); }
+        ++c;
+    }
+    const float Sfin = ctl->S;
+    const int bad = ctl->bad;
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid == 0) {
+            p.lanes[sig * 8 + lane] = bad ? NAN : Sfin;
+            if (p.stats) {
+                uint32_t* o = p.stats + (sig * 8 + lane) * 4;
+                o[0] = n_fast; o[1] = n_group; o[2] = n_slow; o[3] = 0u;
+            }
+        }
+    });
+}
+
+// ---- k_aten_finish: lanes in order, tail, sqrt -------------------------------------------------
+struct AtenFinishParams {
+    int nsig;
+    AtenSrc src[ATEN_MAX_SIGS];
+    const float* lanes;
+    float* out;                 // device [nsig]
+    float* mail;                // optional host-mapped copy
+};
+template <class Ex>
+SM_HD void k_aten_finish(Ex& ex, const AtenFinishParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    ex.each(st, [&](int tid, EmptyState&) {
+        if (tid >= p.nsig) return;
+        const AtenSrc& s = p.src[tid];
+        float tot = p.lanes[tid * 8];
+        for (int l = 1; l < 8; ++l) tot = aten_fadd(tot, p.lanes[tid * 8 + l]);
+        if (s.kind == 0) {
+            const size_t i0 = (s.n / 8) * 8, i4 = i0 + ((s.n - i0) / 4) * 4;
+            for (size_t i = i0; i < i4; ++i) tot = aten_fadd(tot, aten_sq(load_sig1(s.sig, i)));
+            for (size_t i = i4; i < s.n; ++i) tot = aten_fma(load_sig1(s.sig, i), tot);
+        }
+        const float r = sqrtf(tot);
+        p.out[tid] = r;
+        if (p.mail) p.mail[tid] = r;
+    });
+}
+
+// ---- the bias of torch.norm on continuous, Gaussian-like data (host) ---------------------------
+// A K >= 3 tournament's intermediate that stayed in the spectral domain has no spatial values to
+// run the emulation on; its exact norm is known (Parseval).  Its values are sums of ~n spectral
+// terms - Gaussian to the accuracy that matters here - and for y = sigma^2 chi2_1 the expected
+// step of the serial sum inside a binade with ulp u is sigma^2 G(u / sigma^2),
+//     G(rho) = rho * sum_{k>=0} erfc(sqrt((k + 1/2) rho / 2))     (= E[rne(y / u)] u / sigma^2),
+// so a lane's sum follows  dS/di = sigma^2 G(ulp(S) / sigma^2)  binade by binade.  Against
+// torch.norm on Gaussian data: -5.420e-3 vs -5.429e-3 at 67 M elements, and on a real K = 3
+// intermediate (4096^2) -6.89e-4 vs -6.97e-4 (tools/aten_norm_model_check.py).
+inline double aten_gauss_G(double rho) {
+    if (rho <= 1.0) {
+        // the midpoint sum of h(y) = erfc(sqrt(y / 2)) = 1 - sqrt(2/pi) sum_j (-1)^j y^(j+1/2) / (2^j j! (2j+1)) with
+        // step rho: integral (= 1) + sum_j c_j zeta(-(j + 1/2), 1/2) rho^(j + 3/2)  (generalised Euler-Maclaurin;
+        // exact to 3e-9 at rho = 1, 2e-14 at 0.2)
+        static const double c[6] = {-0.04858196661773337, 0.002190834399402349, 0.0001398558838058519,
+                                    -9.613743562329397e-06, -6.822271948485675e-07, 4.934694209977692e-08};
+        const double r = std::sqrt(rho);
+        double pw = rho * r, acc = 1.0;
+        for (int j = 0; j < 6; ++j) { acc += c[j] * pw; pw *= rho; }
+        return acc;
+    }
+    const long kmax = (long)(80.0 / rho) + 4;
+    double sum = 0.0;
+    for (long k = 0; k < kmax; ++k) sum += std::erfc(std::sqrt(((double)k + 0.5) * rho * 0.5));
+    return rho * sum;
+}
+// torch.norm(x) / ||x||_2 for n values of variance sigma^2 (8 lanes of n/8 elements)
+inline double aten_gauss_norm_ratio(double n, double sigma) {
+    if (!(n >= 8) || !(sigma > 0) || !std::isfinite(sigma)) return 1.0;
+    const double s2 = sigma * sigma;
+    double left = std::floor(n / 8.0), S = 0.0;
+    int e = (int)std::floor(std::log2(s2)) - 2;
+    while (left > 0 && e < 127) {
+        const double hi = std::ldexp(1.0, e + 1);
+        if (S >= hi) { ++e; continue; }
+        const double g = s2 * aten_gauss_G(std::ldexp(1.0, e - 23) / s2);
+        const double need = (hi - S) / g;
+        if (need >= left) { S += left * g; left = 0; }
+        else { S = hi; left -= need; ++e; }
+    }
+    const double exact = s2 * std::floor(n / 8.0);
+    return exact > 0 ? std::sqrt(S / exact) : 1.0;
+}
+
+}  // namespace smhip

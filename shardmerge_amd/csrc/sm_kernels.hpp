@@ -2239,6 +2239,8 @@ struct SlerpConstParams {
     float t;
     BlendConsts* out;
     uint32_t* zero_u32; int zero_u32_count;  // candidate-list counters to clear for the next selection (or null)
+    const float* ref_norms;     // norm_mode = reference_cpu: ||v0||, ||v1|| of the gathered class as torch.norm returns
+                                // them on CPU (sm_aten_norm.hpp), or null: the exact norms
 };
 
 // one work-group: sum the partials (fixed order per thread, then the block
@@ -2266,14 +2268,20 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
         BlendConsts c;
         c.thr = p.thr ? *p.thr : 0.f;
         c.s00 = s00; c.s01 = s01; c.s11 = s11; c.n_slerp = (unsigned long long)cnt;
-        double dot = s01 / (sqrt(s00) * sqrt(s11));
+        double n0 = sqrt(s00), n1 = sqrt(s11), rel_bias = 1.0;
+        if (p.ref_norms && s00 > 0 && s11 > 0) {
+            // the reference's cosine divides by ITS norms; F.normalize's norm of (v1 - dot v0) carries about v1's bias
+            rel_bias = (double)p.ref_norms[1] / n1;
+            n0 = (double)p.ref_norms[0]; n1 = (double)p.ref_norms[1];
+        }
+        double dot = s01 / (n0 * n1);
         if (dot > 1.0) dot = 1.0;
         if (dot < -1.0) dot = -1.0;
         const float dotf = (float)dot;
         const float theta = acosf(dotf) * p.t;
         double rel2 = s11 - 2.0 * (double)dotf * s01 + (double)dotf * (double)dotf * s00;
         if (rel2 < 0) rel2 = 0;
-        double reln = sqrt(rel2);
+        double reln = sqrt(rel2) * rel_bias;
         if (reln < 1e-12) reln = 1e-12;
         c.dot = dotf; c.cos_t = cosf(theta); c.sin_t = sinf(theta); c.inv_rel = (float)(1.0 / reln);
         c.pad[0] = c.pad[1] = c.pad[2] = 0.f;
@@ -2659,7 +2667,7 @@ SM_HD void k_delta_norms(Ex& ex, const DeltaNormsParams& p) {
 }
 // ---------------------------------------------------------------------------------
 // norm_mode = reference_cpu: ||x||_2 exactly as torch.norm computes it on CPU for a contiguous
-// fp32 tensor - x*x (rounded) accumulated SERIALLY in 8 fp32 lanes (element i goes to lane i % 8),
+// fp32 tensor - acc = fma(x, x, acc) SERIALLY in 8 fp32 lanes (element i goes to lane i % 8),
 // the lanes then added in order, sqrt.  That sum loses low bits once the running sum is large
 // (-7e-4 at 16 M elements, -5e-3 at 67 M: oracle/norm_bias_probe.py), and the reference's
 // pick-the-larger decisions (|ra| / ||a||  vs  |rb| / ||b||) follow the BIASED norms: an
@@ -2693,7 +2701,7 @@ SM_HD void k_serial_norm(Ex& ex, const SerialNormParams& p) {
                 if (i0 < p.n) load_sig8(sg, i0, v);
                 else { for (int e = 0; e < 8; ++e) v[e] = 0.f; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dst[o * 8 + e] = v[e] * v[e];        // rounded product, then a separate add
+                for (int e = 0; e < 8; ++e) dst[o * 8 + e] = v[e];               // acc = fma(x, x, acc): see sm_aten_norm.hpp
             }
         });
     };
@@ -2715,9 +2723,9 @@ SM_HD void k_serial_norm(Ex& ex, const SerialNormParams& p) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) x[q] = src[(r + q) * 8];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc = acc + x[q];
+                    for (int q = 0; q < 16; ++q) acc = fmaf(x[q], x[q], acc);
                 }
-                for (; r < rows; ++r) acc = acc + src[r * 8];
+                for (; r < rows; ++r) acc = fmaf(src[r * 8], src[r * 8], acc);
                 s.red[0] = (double)acc;
             }
         });

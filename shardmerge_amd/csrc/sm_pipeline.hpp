@@ -13,6 +13,7 @@
 
 #include "../../include/shardmerge_hip.h"
 #include "sm_kernels.hpp"
+#include "sm_aten_norm.hpp"
 
 namespace smhip {
 
@@ -22,6 +23,15 @@ namespace smhip {
         using Params = ParamsT;                                                      \
         static constexpr int waves = 4;                                              \
         static constexpr int max_threads = 1024;                                     \
+        static const char* name() { return NAME; }                                   \
+        template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
+    };
+// the same with explicit launch bounds (work-group size limit, waves per SIMD the registers are budgeted for)
+#define SM_KERNEL_TAG_LB(Tag, ParamsT, NAME, CALL, MAXT, WAVES)                      \
+    struct Tag {                                                                     \
+        using Params = ParamsT;                                                      \
+        static constexpr int waves = WAVES;                                          \
+        static constexpr int max_threads = MAXT;                                     \
         static const char* name() { return NAME; }                                   \
         template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
     };
@@ -161,6 +171,25 @@ SM_KERNEL_TAG(KSpecRescale, SpecRescaleParams, "spec_rescale", k_spec_rescale(ex
 SM_KERNEL_TAG(KDftp, DftpParams, "dft_across_slices", k_dftp(ex, p))
 SM_KERNEL_TAG(KDftpPairs, DftpParams, "dft_across_slices", k_dftp_pairs(ex, p))
 SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
+// (two instantiations each: signals x - base, and the slerp class of two spectrum planes)
+SM_KERNEL_TAG_LB(KAtenPre, AtenPreParams, "aten_norm_pre", k_aten_pre<0>(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenPreC, AtenPreParams, "aten_norm_pre", k_aten_pre<1>(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenScan, AtenScanParams, "aten_norm_scan", k_aten_scan(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenPart, AtenPartParams, "aten_norm_part", k_aten_part<0>(ex, p), 256, 2)      // 16 running summaries per thread
+SM_KERNEL_TAG_LB(KAtenPartC, AtenPartParams, "aten_norm_part", k_aten_part<1>(ex, p), 256, 2)
+SM_KERNEL_TAG_LB(KAtenWalk, AtenWalkParams, "aten_norm_walk", k_aten_walk<0>(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenWalkC, AtenWalkParams, "aten_norm_walk", k_aten_walk<1>(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finish(ex, p), 256, 4)
+// Every kernel is instantiated in smhip_side.hip (one group per translation unit, -DSM_SIDE_GROUP=<g>) or, the
+// static-plan transforms, in smhip_inst.hip; smhip_hip.hip holds host code only.  The build parallelises and a
+// change to the host orchestration does not recompile a single kernel.
+#define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
+#define SM_SIDE_KERNELS_1(X) X(KF2R1) X(KI1R1) X(KPublish) X(KHist) X(KScan) X(KSelect2) X(KSelect2Cull) X(KBlendSel) \
+    X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials)
+#define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
+    X(KCull) X(KAddition) X(KCorrPartial) X(KCorrFinish) X(KSerialNorm) X(KSpecNorm) X(KSumsqCand) X(KSumSpec)       \
+    X(KSpecRescale) X(KDftp) X(KDftpPairs) X(KTranspose)
+#define SM_SIDE_GROUPS 6         // groups 3, 4, 5: the run-time planned (DynPlan) transform kernels
 
 // ---- FFT planner ---------------------------------------------------------------
 struct HostPlan {
@@ -267,7 +296,7 @@ class Pipeline {
     explicit Pipeline(int device) : be(device) {}
     ~Pipeline() {
         for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
-        for (Buffer* b : {&cand_, &t1_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_}) if (b->p) be.free(b->p);
+        for (Buffer* b : {&cand_, &t1_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_, &aten_}) if (b->p) be.free(b->p);
         for (Buffer& b : pool_) if (b.p) be.free(b.p);
         if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
@@ -326,7 +355,7 @@ class Pipeline {
         return SMHIP_OK;
     }
     size_t workspace_bytes() const {
-        size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap;
+        size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap + aten_.cap;
         for (const Buffer& b : inter_) t += b.cap;
         for (const Buffer& b : rowspec_) t += b.cap;
         for (const Buffer& b : pool_) t += b.cap;
@@ -899,9 +928,10 @@ class Pipeline {
 
     // masked slerp sums + constants (reference functions.py:36-43 on the slerp class).
     // fused_parts > 0: the level-2 selection pass already left the sums in d_part().
-    void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts) {
+    void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts, const float* ref_norms = nullptr) {
         const size_t total = (size_t)g.Cb * g.R;
         SlerpConstParams c;
+        c.ref_norms = ref_norms;
         c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
         c.thr = have_thr ? d_thr(0) : nullptr; c.t = t; c.out = d_consts();
         c.zero_u32 = nullptr; c.zero_u32_count = 0;
@@ -1051,7 +1081,19 @@ class Pipeline {
             if (have_cut)
                 run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0),
                            true, &fused);
-            run_slerp_consts(g, have_cut, (float)t, fused);
+            const float* class_norms = nullptr;
+            if (ref_mode_ && !g.full && class_norms_enabled) {
+                // the norms of the gathered class vectors as torch.norm returns them (functions.py:36,40)
+                AtenSrc cs[2];
+                for (int w = 0; w < 2; ++w) {
+                    memset(&cs[w], 0, sizeof(AtenSrc));
+                    cs[w].kind = 1; cs[w].reA = plane(g, P_REA); cs[w].reB = plane(g, P_REB);
+                    cs[w].thr = have_cut ? d_thr(0) : nullptr; cs[w].which = w;
+                    cs[w].R = g.R; cs[w].C = g.Cw; cs[w].Cb = g.Cb; cs[w].n = (size_t)g.Cb * g.R;
+                }
+                if (run_aten_norms(cs, 2, false)) class_norms = d_aten_out();
+            }
+            run_slerp_consts(g, have_cut, (float)t, fused, class_norms);
             const bool spec = cull_pct > 0 && spec_cull && !safe_select && !g.full && (size_t)g.Cb * g.R >= spec_min_bins;
             if (spec) run_blend_spec(g, (float)t_sum, sumsq_parts != nullptr, spec_slot);
             else run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
@@ -1341,20 +1383,99 @@ class Pipeline {
         return true;
     }
 
-    // norm_mode = reference_cpu: the norms as torch's CPU kernel returns them (k_serial_norm).
-    // false: not applicable (n % 8 != 0 or unaligned input) - the caller keeps the exact norms
-    bool run_serial_norms(const SigDesc* sigs, int k, size_t n, double* out) {
-        if (k < 1 || k > 16 || (n % 8) != 0) return false;
-        SerialNormParams q;
-        q.k = k; q.n = n; q.out = mail_->snorm;
-        for (int i = 0; i < 16; ++i) {
-            q.sig[i] = sigs[i < k ? i : 0];
-            if (!aligned16(q.sig[i].x) || !aligned16(q.sig[i].base)) return false;
+    // norm_mode = reference_cpu: norms as torch's CPU kernel returns them (sm_aten_norm.hpp), for up to
+    // ATEN_MAX_SIGS row streams at once.  Results land in d_aten_out()[0..nsig) on the device and, with
+    // to_mail, in mail_->snorm after the caller's next sync.  Needs 16-byte aligned inputs for the
+    // vector loads (false: not applicable, the caller keeps what it has).
+    float* d_aten_out() { return (float*)aten_.p; }
+    float* d_aten_lanes() { return (float*)aten_.p + ATEN_MAX_SIGS; }
+    uint32_t* d_aten_stats() { return (uint32_t*)((float*)aten_.p + ATEN_MAX_SIGS + ATEN_MAX_SIGS * 8); }
+    static constexpr size_t ATEN_HEAD_BYTES = 4096;
+    bool aten_serial = false;          // test hook: the old single-work-group serial chain (k_serial_norm) instead
+    bool class_norms_enabled = true;   // test hook: 0 = reference_cpu leaves the slerp class's norms exact
+    bool ref_mode_ = false;            // the current layer runs with norm_mode = reference_cpu
+    bool run_aten_norms(const AtenSrc* srcs, int nsig, bool to_mail) {
+        if (nsig < 1 || nsig > ATEN_MAX_SIGS) return false;
+        size_t max_rows = 0;
+        const int kind = srcs[0].kind;
+        for (int i = 0; i < nsig; ++i) {
+            const AtenSrc& a = srcs[i];
+            if (a.kind != kind) return false;
+            if (a.kind == 0) { if (!aligned16(a.sig.x) || !aligned16(a.sig.base)) return false; }
+            else if (!aligned16(a.reA) || !aligned16(a.reB)) return false;
+            max_rows = std::max(max_rows, aten_rows(a));
         }
-        be.template launch<KSerialNorm>(k, 256, (LDS_SCRATCH_FLOATS + 2 * SER_CHUNK) * 4, q, stream);
+        const size_t nchunks = std::max<size_t>(1, (max_rows + ATEN_CHUNK_ROWS - 1) / ATEN_CHUNK_ROWS);
+        if (nchunks * nsig > (size_t)1 << 30) return false;
+        const size_t pre_bytes = round_up((size_t)nsig * nchunks * 8 * sizeof(double), 256);
+        const size_t rec_bytes = round_up((size_t)nsig * nchunks * 16 * sizeof(AtenSum), 256);
+        const size_t grp_bytes = round_up((size_t)nsig * nchunks * 16 * ATEN_GROUPS * sizeof(AtenSum), 256);
+        const size_t ep_bytes = round_up((size_t)nsig * nchunks * 8 * sizeof(int), 256);
+        if (ensure(aten_, ATEN_HEAD_BYTES + pre_bytes + rec_bytes + grp_bytes + ep_bytes)) return false;
+        char* basep = (char*)aten_.p + ATEN_HEAD_BYTES;
+        double* pre = (double*)basep;
+        AtenSum* rec = (AtenSum*)(basep + pre_bytes);
+        AtenSum* grp = (AtenSum*)(basep + pre_bytes + rec_bytes);
+        int* epred = (int*)(basep + pre_bytes + rec_bytes + grp_bytes);
+        const bool summaries = nchunks > 1;
+        if (summaries) {
+            AtenPreParams a;
+            a.nsig = nsig; a.nchunks = nchunks; a.pre = pre;
+            for (int i = 0; i < ATEN_MAX_SIGS; ++i) a.src[i] = srcs[i < nsig ? i : 0];
+            if (kind) be.template launch<KAtenPreC>((int)(nchunks * nsig), ATEN_THREADS, LDS_SCRATCH_FLOATS * 4, a, stream);
+            else be.template launch<KAtenPre>((int)(nchunks * nsig), ATEN_THREADS, LDS_SCRATCH_FLOATS * 4, a, stream);
+            AtenScanParams sc;
+            sc.pre = pre; sc.nchunks = nchunks;
+            be.template launch<KAtenScan>(nsig, ATEN_THREADS, (LDS_SCRATCH_FLOATS + 2 * 32 * 8) * 4, sc, stream);
+            AtenPartParams b;
+            b.nsig = nsig; b.nchunks = nchunks; b.prefix = pre; b.rec = rec; b.grp = grp; b.epred = epred;
+            for (int i = 0; i < ATEN_MAX_SIGS; ++i) b.src[i] = srcs[i < nsig ? i : 0];
+            if (kind) be.template launch<KAtenPartC>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
+            else be.template launch<KAtenPart>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
+        }
+        AtenWalkParams w;
+        w.nsig = nsig; w.nchunks = nchunks; w.rec = summaries ? rec : nullptr; w.grp = grp; w.epred = epred;
+        w.lanes = d_aten_lanes(); w.stats = d_aten_stats();
+        for (int i = 0; i < ATEN_MAX_SIGS; ++i) w.src[i] = srcs[i < nsig ? i : 0];
+        if (kind) be.template launch<KAtenWalkC>(nsig * 8, ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_WALK_LDS_FLOATS) * 4, w, stream);
+        else be.template launch<KAtenWalk>(nsig * 8, ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_WALK_LDS_FLOATS) * 4, w, stream);
+        AtenFinishParams f;
+        f.nsig = nsig; f.lanes = d_aten_lanes(); f.out = d_aten_out(); f.mail = to_mail ? mail_->snorm : nullptr;
+        for (int i = 0; i < ATEN_MAX_SIGS; ++i) f.src[i] = srcs[i < nsig ? i : 0];
+        be.template launch<KAtenFinish>(1, 64, LDS_SCRATCH_FLOATS * 4, f, stream);
+        return true;
+    }
+    // the delta / fp32 norms of `k` signals of n elements each -> out[] (one sync)
+    bool run_serial_norms(const SigDesc* sigs, int k, size_t n, double* out) {
+        if (k < 1 || k > 16) return false;
+        if (aten_serial) {
+            if ((n % 8) != 0) return false;
+            SerialNormParams q;
+            q.k = k; q.n = n; q.out = mail_->snorm;
+            for (int i = 0; i < 16; ++i) {
+                q.sig[i] = sigs[i < k ? i : 0];
+                if (!aligned16(q.sig[i].x) || !aligned16(q.sig[i].base)) return false;
+            }
+            be.template launch<KSerialNorm>(k, 256, (LDS_SCRATCH_FLOATS + 2 * SER_CHUNK) * 4, q, stream);
+        } else {
+            AtenSrc srcs[ATEN_MAX_SIGS];
+            for (int i = 0; i < k; ++i) {
+                memset(&srcs[i], 0, sizeof(AtenSrc));
+                srcs[i].kind = 0; srcs[i].sig = sigs[i]; srcs[i].n = n; srcs[i].C = -1;
+            }
+            if (!run_aten_norms(srcs, k, true)) return false;
+        }
         be.sync(stream);
         for (int i = 0; i < k; ++i) out[i] = (double)mail_->snorm[i];
         return true;
+    }
+    // test hook: walker statistics of the last run_aten_norms, summed over lanes: chunks composed from their
+    // summaries / crossed with the help of the group summaries / walked cooperatively
+    void aten_stats(int nsig, unsigned long long* out3) {
+        std::vector<uint32_t> h((size_t)nsig * 32);
+        be.d2h(h.data(), d_aten_stats(), h.size() * 4, stream);
+        out3[0] = out3[1] = out3[2] = 0;
+        for (int i = 0; i < nsig * 8; ++i) for (int q = 0; q < 3; ++q) out3[q] += h[4 * i + q];
     }
 
     // row spectra of every raw delta (row-pair F1 each) + their norms with ONE sync
@@ -1467,8 +1588,10 @@ class Pipeline {
         memset(&rp, 0, sizeof rp);
         rp.merged_delta_norm = -1;
 
-        const bool ref_norms = d.norm_mode == 1;       // torch's CPU norm kernel emulated for every spatial norm
-        const bool spectral_ok = spectral_inter && (Rs % 2 == 0) && Rs >= 2 && !ref_norms;   // (ref_norms needs the spatial intermediate)
+        const bool ref_norms = d.norm_mode == 1;       // torch's CPU norm kernel emulated for every norm the reference takes
+        struct RefModeGuard { bool& f; ~RefModeGuard() { f = false; } } ref_guard{ref_mode_};
+        ref_mode_ = ref_norms;
+        const bool spectral_ok = spectral_inter && (Rs % 2 == 0) && Rs >= 2;
         std::vector<Slot> stack(d.k);
         for (int i = 0; i < d.k; ++i) {
             stack[i].sig = SigDesc{d.finetune[i], d.base[i], d.in_dtype, 1.f};
@@ -1726,9 +1849,14 @@ class Pipeline {
                             spec_slot.spectral = true;
                             spec_slot.re_id = pidx_[P_RER]; spec_slot.im_id = pidx_[P_IMA];
                             spec_slot.thr = have_cull ? mail_->thr[1] : 0.f;
-                            spec_slot.spec_scale = ssum > 0 ? 1.0 / std::sqrt(ssum) : 1.0;
+                            // reference_cpu: the reference takes torch.norm of the materialised tensor
+                            // (fast_fourier.py:209-210, functions.py:85); here the tensor does not exist - its norm
+                            // is modelled from its exact one (aten_gauss_norm_ratio: the values are Gaussian-like)
+                            const double nrm_exact = target_norm * std::sqrt(ssum);
+                            const double bias = ref_norms ? aten_gauss_norm_ratio((double)n, nrm_exact / std::sqrt((double)n)) : 1.0;
+                            spec_slot.spec_scale = ssum > 0 ? 1.0 / (std::sqrt(ssum) * bias) : 1.0;
                             spec_slot.post = target_norm;
-                            spec_slot.norm = target_norm * std::sqrt(ssum);
+                            spec_slot.norm = nrm_exact * bias;
                             spec_slot.sig = SigDesc{nullptr, nullptr, DT_F32, 1.f};
                             const int r1 = pool_acquire(g.plane_floats * sizeof(float));
                             const int r2 = pool_acquire(g.plane_floats * sizeof(float));
@@ -1937,7 +2065,7 @@ class Pipeline {
     // profiling table lives in the backend
   private:
     std::map<int, HostPlan> plans_;
-    Buffer t1_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_;
+    Buffer t1_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_, aten_;
     std::vector<Buffer> pool_ = std::vector<Buffer>(4);
     std::vector<char> pool_busy_ = std::vector<char>(4, 1);
     int pidx_[4] = {0, 1, 2, 3};

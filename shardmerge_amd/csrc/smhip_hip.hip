@@ -20,6 +20,10 @@ namespace smhip {
 #define SM_DECL_PLAN(...) SM_FFT_KERNELS_OF(SM_DECL_EXTERN, __VA_ARGS__)
 SM_STATIC_PLANS(SM_DECL_PLAN)
 #undef SM_DECL_PLAN
+SM_SIDE_KERNELS_0(SM_DECL_EXTERN)
+SM_SIDE_KERNELS_1(SM_DECL_EXTERN)
+SM_SIDE_KERNELS_2(SM_DECL_EXTERN)
+SM_FFT_KERNELS_OF(SM_DECL_EXTERN, DynPlan)
 #undef SM_DECL_EXTERN
 
 struct HipBackend {

@@ -192,6 +192,20 @@ class Engine:
             self.ctx.h, v0.data_ptr(), v1.data_ptr(), r, c, float(t), 1 if agreement else 0, out.data_ptr(), self._stream()))
         return out
 
+    # -- torch.norm as ATen's CPU kernel computes it (norm_mode = reference_cpu) -----------------
+    def reference_cpu_norm(self, x: torch.Tensor, base: Optional[torch.Tensor] = None) -> float:
+        """``torch.norm(x - base)`` exactly as the reference's ``device="cpu"`` run gets it for a contiguous
+        fp32 tensor (functions.py:85, fast_fourier.py:152,209-210): bit-identical, computed in parallel."""
+        dtype = x.dtype if x.dtype in _DTYPE_CODE and (base is None or base.dtype == x.dtype) else torch.float32
+        xs = self._dev(x, dtype)
+        bs = self._dev(base, dtype) if base is not None else None
+        if bs is not None and bs.shape != xs.shape:
+            raise ValueError(f"shape mismatch: {tuple(xs.shape)} vs {tuple(bs.shape)}")
+        out = C.c_float(0.0)
+        self._call(self.lib.dll.smhip_reference_cpu_norm(self.ctx.h, xs.data_ptr(), bs.data_ptr() if bs is not None else None,
+                                                         _DTYPE_CODE[dtype], xs.numel(), C.byref(out), self._stream()))
+        return float(out.value)
+
     # -- N3: AdditionMerge / TaskAdditionMerge ---------------------------------------------
     def addition_merge(self, finetunes: Sequence[torch.Tensor], base: torch.Tensor, sign_agreement: bool = False) -> torch.Tensor:
         """sum_i (finetune_i - base) in the tensors' dtype, optionally masked by the majority sign
