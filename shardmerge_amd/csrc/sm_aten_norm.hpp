@@ -78,7 +78,11 @@ SM_HD size_t aten_rows(const AtenSrc& s) { return s.kind == 0 ? s.n / 8 : (s.n +
 
 SM_HD float aten_sq(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __fmul_rn(v, v);
+    // a ROUNDED product: HIP's __fmul_rn is a plain multiply, which the compiler (fp-contract=fast on the device)
+    // fuses with the add that follows - the empty asm keeps the two apart
+    float r = v * v;
+    asm volatile("" : "+v"(r));
+    return r;
 #else
     volatile float r = v * v;
     return r;
@@ -93,7 +97,9 @@ SM_HD float aten_fma(float x, float s) {        // fl(x * x + s), one rounding
 }
 SM_HD float aten_fadd(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __fadd_rn(a, b);                    // never contracted with the multiply that made b
+    float r = a + b;
+    asm volatile("" : "+v"(r));
+    return r;
 #else
     volatile float r = a + b;
     return r;
@@ -301,8 +307,9 @@ struct AtenPartParams {
     AtenSrc src[ATEN_MAX_SIGS];
     size_t nchunks;
     const double* prefix;       // [nsig][nchunks][8]: (estimated) sum of the lane's squares up to the END of the chunk:
-                                // the running sum trails it slightly, so it meets the chunk in that binade or the one
-                                // below - and a chunk in which it moves up a binade has summaries for both
+                                // the running sum trails it slightly (or leads it by less than ATEN_LEAD_MARGIN), so it
+                                // meets the chunk in the binade of prefix * (1 + margin) or the one below - and a chunk
+                                // in which it moves up a binade has summaries for both
     AtenSum* rec;               // [nsig][nchunks][8][2]
     AtenSum* grp;               // [nsig][nchunks][8][2][32]: the same per group of 256 rows (8 threads)
     int* epred;                 // [nsig][nchunks][8]
@@ -342,12 +349,14 @@ SM_HD void aten_acc_add2(AtenAcc& coarse, AtenAcc& fine, float x, double scale_f
 // The chunk goes through LDS in ATEN_STAGES stages of 8 rows per thread: the loads are coalesced (8
 // consecutive threads fetch 8 consecutive rows), each thread then reads ITS 8 rows back - a thread's
 // rows must be consecutive for its summary to mean anything.
-constexpr double ATEN_LAG_MARGIN = 0.2;         // how far below the exact prefix the running sum is allowed for
+constexpr double ATEN_LAG_MARGIN = 0.2;         // how far below the estimated prefix the running sum is allowed for
+constexpr double ATEN_LEAD_MARGIN = 0.02;       // ... and how far above (lattice data round UP on balance; the estimate
+                                                // comes from a sample)
 constexpr int ATEN_STAGE_ROWS = 8;
 constexpr int ATEN_STAGES = ATEN_ROWS_PER_THREAD / ATEN_STAGE_ROWS;
 constexpr int ATEN_STAGE_PITCH = ATEN_STAGE_ROWS * 8 + 4;          // floats per thread: 256 B + 16 B (bank spread)
 constexpr size_t ATEN_PART_LDS_FLOATS = (size_t)ATEN_THREADS * ATEN_STAGE_PITCH + ATEN_THREADS * ATEN_STAGE_ROWS / 4 + 64;
-struct AtenPartState { AtenAcc a[16]; AtenSum s[16]; double red[8]; };
+struct AtenPartState { AtenAcc a[16]; AtenSum s[16]; float pf[ATEN_STAGE_ROWS][8]; uint32_t pw[ATEN_STAGE_ROWS]; double red[8]; };
 template <int KIND, class Ex>
 SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     typename Ex::template State<AtenPartState> st;
@@ -368,34 +377,45 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     int ep[8];
     uint32_t two = 0u;
     for (int l = 0; l < 8; ++l) {
-        ep[l] = aten_exp_of(p.prefix[slot + l]);
+        ep[l] = aten_exp_of(p.prefix[slot + l] * (1.0 + ATEN_LEAD_MARGIN));
         const double before = chunk > 0 ? p.prefix[slot - 8 + l] : 0.0;
         if (ep[l] == ATEN_NO_EXP || aten_exp_of(before * (1.0 - ATEN_LAG_MARGIN)) != ep[l]) two |= 1u << l;
     }
-    ex.each(st, [&](int, AtenPartState& q) {
+    const size_t row0 = chunk * ATEN_CHUNK_ROWS;
+    // stage `sidx`: this thread fetches rows q = i * 256 + tid of it (owner q / 8, the owner's row q % 8): 8
+    // consecutive threads read 8 consecutive rows
+    auto fetch = [&](int tid, AtenPartState& q, int sidx) {
+#pragma unroll
+        for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
+            const int qq = i * ATEN_THREADS + tid;
+            const size_t r = row0 + (size_t)(qq / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (qq % 8);
+            uint32_t w2 = 0u;
+            if (r < rows) w2 = aten_load_row<KIND>(s, wr, thr, r, q.pf[i]);
+            else { for (int e = 0; e < 8; ++e) q.pf[i][e] = 0.f; }
+            q.pw[i] = w2;
+        }
+    };
+    ex.each(st, [&](int tid, AtenPartState& q) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) aten_acc_zero(q.a[i]);         // [lane][cand]: cand 0 = ep, cand 1 = ep - 1
+        fetch(tid, q, 0);
     });
-    const size_t row0 = chunk * ATEN_CHUNK_ROWS;
     for (int sidx = 0; sidx < ATEN_STAGES; ++sidx) {
         if (row0 + (size_t)sidx * ATEN_STAGE_ROWS >= rows) break;   // (uniform) nothing left: thread 0's rows are past the end
-        ex.each(st, [&](int tid, AtenPartState&) {
+        ex.each(st, [&](int tid, AtenPartState& q) {
 #pragma unroll
             for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
-                const int q = i * ATEN_THREADS + tid;                       // row of the stage: owner q / 8, its row q % 8
-                const size_t r = row0 + (size_t)(q / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (q % 8);
-                float y[8];
-                uint32_t w2 = 0u;
-                if (r < rows) w2 = aten_load_row<KIND>(s, wr, thr, r, y);
-                else { for (int e = 0; e < 8; ++e) y[e] = 0.f; }
-                float* d = stage + (size_t)(q / 8) * ATEN_STAGE_PITCH + (q % 8) * 8;
-                cf4 lo = {y[0], y[1], y[2], y[3]}, hi = {y[4], y[5], y[6], y[7]};
+                const int qq = i * ATEN_THREADS + tid;
+                float* d = stage + (size_t)(qq / 8) * ATEN_STAGE_PITCH + (qq % 8) * 8;
+                cf4 lo = {q.pf[i][0], q.pf[i][1], q.pf[i][2], q.pf[i][3]}, hi = {q.pf[i][4], q.pf[i][5], q.pf[i][6], q.pf[i][7]};
                 ((cf4*)d)[0] = lo; ((cf4*)d)[1] = hi;
-                if (KIND == 1) w2row[q] = (uint8_t)w2;
+                if (KIND == 1) w2row[qq] = (uint8_t)q.pw[i];
             }
         });
         ex.sync();
         ex.each(st, [&](int tid, AtenPartState& q) {
+            // the next stage's loads are in flight while this one is summarised
+            if (sidx + 1 < ATEN_STAGES) fetch(tid, q, sidx + 1);
             double scale[8];
 #pragma unroll
             for (int l = 0; l < 8; ++l) scale[l] = ep[l] == ATEN_NO_EXP ? 0.0 : aten_pow2(24 - ep[l]);
@@ -458,9 +478,10 @@ struct AtenWalkParams {
 };
 // LDS of the walker (floats past LDS_SCRATCH_FLOATS)
 constexpr int ATEN_YPITCH = ATEN_ROWS_PER_THREAD + 1;
-constexpr int ATEN_WALK_LDS_FLOATS = ATEN_THREADS * ATEN_YPITCH + ATEN_THREADS + 4 * (2 * ATEN_THREADS + 16) + 16;
+constexpr int ATEN_WALK_LDS_FLOATS = ATEN_THREADS * ATEN_YPITCH + ATEN_THREADS + 4 * (2 * ATEN_THREADS + 16) + 16 + ATEN_THREADS + 4 * 2 * 32;
 constexpr int ATEN_SERIAL0 = 64;                // thread ranges a fresh sum is carried through serially (2048 elements)
 struct AtenCtl { float S; int t_first; double m_at; double m_end; int bad; int pad; };
+struct AtenWalkState { AtenSum c0, c1; int ep; };
 
 // entries ent[0..255] applied in order to m0 (binade e): first entry after which m >= 2^24 (or
 // that is a "stop") -> ctl.t_first (256: none), m in front of it -> ctl.m_at (= m after all of them
@@ -479,19 +500,35 @@ SM_HD void aten_resolve(Ex& ex, StT& st, const AtenSum* ent, AtenSum* pre, AtenS
     ex.each(st, [&](int tid, S&) {
         if (tid != 0) return;
         const double lim = 16777216.0;
+        AtenSum sg[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sg[g] = seg[g];                       // all 16 reads in flight together
         double m = (double)m0;
         uint32_t odd = m0 & 1u;
+        int gf = 16;                                                        // first segment that does not pass
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const double mg = aten_apply(m, odd, sg[g]);
+            const bool pass = gf == 16 && mg < lim;
+            if (gf == 16 && !pass) gf = g;
+            if (pass) { m = mg; odd = (uint32_t)((unsigned long long)mg & 1ull); }
+        }
         int tf = 256;
-        for (int g = 0; g < 16 && tf == 256; ++g) {
-            const double mg = aten_apply(m, odd, seg[g]);
-            if (mg < lim) { m = mg; odd = (uint32_t)((unsigned long long)mg & 1ull); continue; }
+        if (gf < 16) {
+            AtenSum pr[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pr[j] = pre[gf * 16 + j];
             double prev = m;
+            int jf = 16;
+#pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double mj = aten_apply(m, odd, pre[g * 16 + j]);
-                if (!(mj < lim)) { tf = g * 16 + j; break; }
-                prev = mj;
+                const double mj = aten_apply(m, odd, pr[j]);
+                const bool pass = jf == 16 && mj < lim;
+                if (jf == 16 && !pass) jf = j;
+                if (pass) prev = mj;
             }
-            if (tf == 256) tf = g * 16 + 15;        // (cannot happen: the segment total is its last prefix)
+            if (jf == 16) jf = 15;                  // (cannot happen: the segment total is its last prefix)
+            tf = gf * 16 + jf;
             m = prev;
         }
         ctl->t_first = tf; ctl->m_at = m; ctl->m_end = m;
@@ -501,7 +538,7 @@ SM_HD void aten_resolve(Ex& ex, StT& st, const AtenSum* ent, AtenSum* pre, AtenS
 
 template <int KIND, class Ex>
 SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
-    typename Ex::template State<EmptyState> st;
+    typename Ex::template State<AtenWalkState> st;
     ex.init(st);
     const int sig = ex.bid() / 8, lane = ex.bid() % 8;
     const AtenSrc& s = p.src[sig];
@@ -515,12 +552,14 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
     AtenSum* pre = ent + ATEN_THREADS;                                      // [256]
     AtenSum* seg = pre + ATEN_THREADS;                                      // [16]
     AtenCtl* ctl = (AtenCtl*)(seg + 16);
-    ex.each(st, [&](int tid, EmptyState&) { if (tid == 0) { ctl->S = 0.f; ctl->bad = 0; ctl->t_first = 0; } });
+    int* epw = (int*)(ctl + 1);                                             // [256]: the window's predictions
+    AtenSum* gsum = (AtenSum*)(epw + ATEN_THREADS);                         // [2][32]: a chunk's group summaries
+    ex.each(st, [&](int tid, AtenWalkState&) { if (tid == 0) { ctl->S = 0.f; ctl->bad = 0; ctl->t_first = 0; } });
     ex.sync();
     uint32_t n_fast = 0, n_group = 0, n_slow = 0;
 
     auto set_S = [&](float v) {                     // (callers have a barrier behind their last read of ctl)
-        ex.each(st, [&](int tid, EmptyState&) {
+        ex.each(st, [&](int tid, AtenWalkState&) {
             if (tid == 0) { ctl->S = v; if (!(v - v == 0.f)) ctl->bad = 1; }
         });
         ex.sync();
@@ -528,7 +567,7 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
     // thread ranges [t0, t1] of the staged data (32 elements each), added serially by one thread; a range
     // is read into registers before its chain of dependent fmas starts
     auto serial_add = [&](float S, int t0, int t1) {
-        ex.each(st, [&](int tid, EmptyState&) {
+        ex.each(st, [&](int tid, AtenWalkState&) {
             if (tid != 0) return;
             float acc = S;
             for (int t = t0; t <= t1; ++t) {
@@ -555,10 +594,10 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
     // rows [r0, r0 + nrows) of this lane -> ybuf / wbits in thread-range order (nrows <= ATEN_CHUNK_ROWS)
     auto stage_rows = [&](size_t r0, int nrows) {
         if (KIND == 1) {
-            ex.each(st, [&](int tid, EmptyState&) { wbits[tid] = 0u; });
+            ex.each(st, [&](int tid, AtenWalkState&) { wbits[tid] = 0u; });
             ex.sync();
         }
-        ex.each(st, [&](int tid, EmptyState&) {
+        ex.each(st, [&](int tid, AtenWalkState&) {
             for (int j = tid; j < nrows; j += ATEN_THREADS) {               // coalesced
                 const size_t r = r0 + (size_t)j;
                 bool twice = false;
@@ -580,7 +619,7 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
             int ec = 0; uint32_t mc = 0;
             const bool nrm = aten_split(Sc, ec, mc);
             const double scale = nrm ? aten_pow2(23 - ec) : 0.0;
-            ex.each(st, [&](int tid, EmptyState&) {
+            ex.each(st, [&](int tid, AtenWalkState&) {
                 AtenSum v = aten_sum_identity();
                 if (tid >= lo) {
                     const float* yy = ybuf + tid * ATEN_YPITCH;
@@ -619,83 +658,108 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
         }
     };
 
+    // chunk cx (window entry `me` holds its prediction) leaves binade e, or was summarised for another one
+    auto cross_chunk = [&](size_t cx, int ep, int e, float Sin) -> bool {
+        const size_t slot = ((size_t)sig * p.nchunks + cx) * 8 + lane;
+        const int k0 = ep - e;
+        if (ep == ATEN_NO_EXP || !(k0 == 0 || k0 == 1)) return false;
+        // its 32 group summaries (both candidates) find the group of 256 rows that holds the crossing; that
+        // group is added serially, the groups behind it are composed in the binade the sum has moved to
+        uint32_t me = 0; int ee = 0;
+        aten_split(Sin, ee, me);
+        ex.each(st, [&](int tid, AtenWalkState&) {
+            if (tid < 2 * ATEN_GROUPS) gsum[tid] = p.grp[(slot * 2 + (tid / ATEN_GROUPS)) * ATEN_GROUPS + (tid % ATEN_GROUPS)];
+        });
+        ex.sync();
+        ex.each(st, [&](int tid, AtenWalkState&) { ent[tid] = tid < ATEN_GROUPS ? gsum[k0 * ATEN_GROUPS + tid] : aten_sum_identity(); });
+        ex.sync();
+        aten_resolve(ex, st, ent, pre, seg, me, ctl);
+        const int g = ctl->t_first;
+        const float Sg = aten_join(e, ctl->m_at);
+        ex.sync();
+        if (g >= ATEN_GROUPS) return false;
+        stage_rows(cx * ATEN_CHUNK_ROWS + (size_t)g * ATEN_GROUP_ROWS, ATEN_GROUP_ROWS);
+        serial_add(Sg, 0, ATEN_GROUP_ROWS / ATEN_ROWS_PER_THREAD - 1);
+        if (ctl->bad) return true;
+        const float S2 = ctl->S;
+        int e2 = 0; uint32_t m2 = 0;
+        const bool n2 = aten_split(S2, e2, m2);
+        const int k2 = ep - e2;
+        if (!(n2 && (k2 == 0 || k2 == 1))) return false;
+        ex.each(st, [&](int tid, AtenWalkState&) {
+            ent[tid] = (tid > g && tid < ATEN_GROUPS) ? gsum[k2 * ATEN_GROUPS + tid] : aten_sum_identity();
+        });
+        ex.sync();
+        aten_resolve(ex, st, ent, pre, seg, m2, ctl);
+        const int g2 = ctl->t_first;
+        const float S3 = aten_join(e2, ctl->m_at);
+        ex.sync();
+        if (g2 < ATEN_THREADS) return false;            // a second crossing in the same chunk
+        set_S(S3);
+        return true;
+    };
+
     size_t c = 0;
     while (c < nch) {
         if (ctl->bad) break;
-        int e = 0; uint32_t m0 = 0;
-        const float S0 = ctl->S;
-        const bool normal = aten_split(S0, e, m0);
-        if (!(normal && p.rec)) { ++n_slow; walk_chunk(c); ++c; continue; }
-        // chunks c .. c+255 whose summary was made for binade e
-        ex.each(st, [&](int tid, EmptyState&) {
+        {
+            int e0 = 0; uint32_t m0 = 0;
+            if (!(aten_split(ctl->S, e0, m0) && p.rec)) { ++n_slow; walk_chunk(c); ++c; continue; }
+        }
+        // a window of 256 chunks: both summaries and the prediction of chunk c + t stay with thread t
+        ex.each(st, [&](int tid, AtenWalkState& q) {
             const size_t cc = c + tid;
-            AtenSum v = aten_sum_identity();
+            q.ep = ATEN_NO_EXP; q.c0 = aten_sum_identity(); q.c1 = aten_sum_identity();
             if (cc < nch) {
                 const size_t slot = ((size_t)sig * p.nchunks + cc) * 8 + lane;
-                const int k = p.epred[slot] - e;
-                v = (p.epred[slot] != ATEN_NO_EXP && (k == 0 || k == 1)) ? p.rec[slot * 2 + k] : aten_sum_stop();
+                q.ep = p.epred[slot]; q.c0 = p.rec[slot * 2]; q.c1 = p.rec[slot * 2 + 1];
             }
-            ent[tid] = v;
+            epw[tid] = q.ep;
         });
         ex.sync();
-        aten_resolve(ex, st, ent, pre, seg, m0, ctl);
-        const int adv = ctl->t_first;
-        const float Snew = aten_join(e, ctl->m_at);
-        ex.sync();
-        set_S(Snew);
-        const size_t left = nch - c;
-        const size_t took = (size_t)adv < left ? (size_t)adv : left;
-        n_fast += (uint32_t)took;
-        c += took;
-        if (adv == 256 || c >= nch) continue;
-        // ---- chunk c leaves binade e (or was summarised for another one) ----------------------------
-        const size_t slot = ((size_t)sig * p.nchunks + c) * 8 + lane;
-        const int ep = p.epred[slot];
-        const int k0 = ep - e;
-        bool done = false;
-        if (ep != ATEN_NO_EXP && (k0 == 0 || k0 == 1)) {
-            // its 32 group summaries find the group of 256 rows that holds the crossing; that group is
-            // added serially, the groups behind it are composed in the binade the sum has moved to
-            uint32_t me = 0; int ee = 0;
-            aten_split(Snew, ee, me);                                       // (= e, m after the chunks composed)
-            ex.each(st, [&](int tid, EmptyState&) {
-                ent[tid] = tid < ATEN_GROUPS ? p.grp[(slot * 2 + k0) * ATEN_GROUPS + tid] : aten_sum_identity();
+        const size_t wbase = c;
+        int woff = 0;
+        while (woff < ATEN_THREADS && wbase + woff < nch) {
+            if (ctl->bad) break;
+            int e = 0; uint32_t m0 = 0;
+            const float Sw = ctl->S;
+            if (!aten_split(Sw, e, m0)) break;
+            ex.each(st, [&](int tid, AtenWalkState& q) {
+                AtenSum v = aten_sum_identity();
+                if (tid >= woff && wbase + tid < nch) {
+                    const int k = q.ep - e;
+                    v = (q.ep != ATEN_NO_EXP && k == 0) ? q.c0 : (q.ep != ATEN_NO_EXP && k == 1) ? q.c1 : aten_sum_stop();
+                }
+                ent[tid] = v;
             });
             ex.sync();
-            aten_resolve(ex, st, ent, pre, seg, me, ctl);
-            const int g = ctl->t_first;
-            const float Sg = aten_join(e, ctl->m_at);
+            aten_resolve(ex, st, ent, pre, seg, m0, ctl);
+            const int adv = ctl->t_first;
+            const float Snew = aten_join(e, ctl->m_at);
             ex.sync();
-            if (g < ATEN_GROUPS) {
-                stage_rows(c * ATEN_CHUNK_ROWS + (size_t)g * ATEN_GROUP_ROWS, ATEN_GROUP_ROWS);
-                serial_add(Sg, 0, ATEN_GROUP_ROWS / ATEN_ROWS_PER_THREAD - 1);
-                const float S2 = ctl->S;
-                int e2 = 0; uint32_t m2 = 0;
-                const bool n2 = aten_split(S2, e2, m2);
-                const int k2 = ep - e2;
-                if (ctl->bad) { done = true; }
-                else if (n2 && (k2 == 0 || k2 == 1)) {
-                    ex.each(st, [&](int tid, EmptyState&) {
-                        ent[tid] = (tid > g && tid < ATEN_GROUPS) ? p.grp[(slot * 2 + k2) * ATEN_GROUPS + tid] : aten_sum_identity();
-                    });
-                    ex.sync();
-                    aten_resolve(ex, st, ent, pre, seg, m2, ctl);
-                    const int g2 = ctl->t_first;
-                    const float S3 = aten_join(e2, ctl->m_at);
-                    ex.sync();
-                    if (g2 >= ATEN_THREADS) { set_S(S3); done = true; ++n_group; }
-                }
-            }
-            if (!done) set_S(Snew);                                         // a second crossing (or a prediction two binades off): from the top
+            set_S(Snew);
+            const int upto = adv < ATEN_THREADS ? adv : ATEN_THREADS;
+            const size_t avail = nch - wbase;
+            const int lim = (size_t)upto < avail ? upto : (int)avail;
+            n_fast += (uint32_t)(lim - woff);
+            woff = lim;
+            if (adv >= ATEN_THREADS || wbase + woff >= nch) break;
+            const size_t cx = wbase + woff;
+            if (cross_chunk(cx, epw[woff], e, Snew)) ++n_group;
+            else if (!ctl->bad) { set_S(Snew); ++n_slow; walk_chunk(cx); }
+            ++woff;
         }
-        if (!done) { ++n_slow; walk_chunk(c); }
-        ++c;
+        c = wbase + (size_t)woff;
+        if (woff == 0) { ++n_slow; walk_chunk(c); ++c; }    // (S left the normal range inside the window loop)
     }
     const float Sfin = ctl->S;
     const int bad = ctl->bad;
-    ex.each(st, [&](int tid, EmptyState&) {
+    ex.each(st, [&](int tid, AtenWalkState&) {
         if (tid == 0) {
-            p.lanes[sig * 8 + lane] = bad ? NAN : Sfin;
+            // a sum that went non-finite is reported as it stood (a NaN BEHIND an overflow to Inf would turn torch's
+            // result into NaN; either way the layer merge refuses the tensor: SMHIP_ERR_NONFINITE)
+            p.lanes[sig * 8 + lane] = Sfin;
+            (void)bad;
             if (p.stats) {
                 uint32_t* o = p.stats + (sig * 8 + lane) * 4;
                 o[0] = n_fast; o[1] = n_group; o[2] = n_slow; o[3] = 0u;

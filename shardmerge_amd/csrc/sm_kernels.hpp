@@ -2239,22 +2239,153 @@ struct SlerpConstParams {
     float t;
     BlendConsts* out;
     uint32_t* zero_u32; int zero_u32_count;  // candidate-list counters to clear for the next selection (or null)
-    const float* ref_norms;     // norm_mode = reference_cpu: ||v0||, ||v1|| of the gathered class as torch.norm returns
-                                // them on CPU (sm_aten_norm.hpp), or null: the exact norms
+    const float* ref_norms;     // norm_mode = reference_cpu, ordered emulation (test hook): ||v0||, ||v1|| of the gathered
+                                // class as torch.norm returns them on CPU (sm_aten_norm.hpp), or null
+    const double* emf_part;     // norm_mode = reference_cpu: k_class_emf's partials [emf_nparts][2 * EMF_VALS] (or null)
+    int emf_nparts;
+    int emf_elo;                // binade of its first rounding level
 };
+
+// ---- norm_mode = reference_cpu: what torch.norm makes of the gathered slerp-class vectors -----------------------
+// (reference functions.py:36,40: v0.norm(), v1.norm() on fp32 CPU tensors of ~0.4 n elements.)  ATen's kernel
+// accumulates fma(x, x, acc) serially in 8 fp32 lanes (sm_aten_norm.hpp), which loses low bits once a lane's sum is
+// large: -2e-4 at 16 M elements, -1.5e-3 at 67 M.  The reference's cosine is taken with THOSE norms.  Bit-identity
+// is not on offer here (the reference gathers its own spectrum's values in its own order), but the bias is a
+// statistical property of the values: while a lane's sum S sits in the binade with ulp u, an element moves it by
+// rne(x^2 / u) u, so with g(u) = the class mean of that quantity the sum follows dS/di = g(ulp(S)) binade by binade.
+// k_class_emf takes g for EMF_LEVELS consecutive binades (and the exact mean) from a sample of the planes (all of
+// them below 4 M elements, 1 piece in 16 from 64 M on); k_slerp_consts integrates the trajectory for cnt / 8 elements per lane and scales the exact norm by the
+// ratio.  Against torch.norm on the reference's own gathered vectors: 1e-6 ... 4e-6 where the exact norm is off by
+// 2e-4 (4096^2; tools/aten_norm_model_check.py); the ordered emulation of sm_aten_norm.hpp (test hook
+// "class_norms" = 2) gives the same to 2e-6.
+constexpr int EMF_LEVELS = 16;
+constexpr int EMF_VALS = EMF_LEVELS + 2;        // weighted count, sum of squares, EMF_LEVELS sums of rounded squares
+constexpr int EMF_MAX_SAMPLE = 16;              // at most one piece of 8 rows (64 plane elements) in every 16 is read ...
+constexpr size_t EMF_MIN_SAMPLED = (size_t)4 << 20;   // ... as long as this many elements are
+struct ClassEmfParams {
+    const float* reA; const float* reB;         // planes [Cb][R]
+    const float* thr;                           // device scalar (cutoff threshold) or null (-> 0)
+    int R, C, Cb;
+    size_t n;                                   // plane elements
+    int elo;                                    // level k rounds to multiples of 2^(elo + k - 23)
+    int sample;                                 // one piece of 8 rows in every `sample`
+    int iters;                                  // pieces per 8 threads
+    double* partials;                           // [grid][2 * EMF_VALS]
+};
+struct EmfState { double red[2 * EMF_VALS]; };
+SM_HD double emf_pow2(int e) {
+    if (e < -1000) e = -1000;
+    if (e > 1000) e = 1000;
+    const unsigned long long b = (unsigned long long)(1023 + e) << 52;
+    double d; memcpy(&d, &b, 8); return d;
+}
+template <class Ex>
+SM_HD void k_class_emf(Ex& ex, const ClassEmfParams& p) {
+    typename Ex::template State<EmfState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();                       // 256: 32 pieces of 8 rows per sweep
+    const size_t rows = (p.n + 7) / 8;
+    const size_t npieces = (rows + 8 * (size_t)p.sample - 1) / (8 * (size_t)p.sample);
+    const float thr = p.thr ? *p.thr : 0.f;
+    const WeightRanges wr = weight_ranges(p.R, p.C, p.Cb);
+    const double sc0 = emf_pow2(23 - p.elo);
+    ex.each(st, [&](int tid, EmfState& q) {
+        double acc[2 * EMF_VALS];
+#pragma unroll
+        for (int i = 0; i < 2 * EMF_VALS; ++i) acc[i] = 0.0;
+        for (int it = 0; it < p.iters; ++it) {
+            const size_t piece = ((size_t)ex.bid() * p.iters + it) * (nt / 8) + (size_t)(tid / 8);
+            const size_t r = piece * (8 * (size_t)p.sample) + (size_t)(tid % 8);
+            if (piece >= npieces || r >= rows) continue;
+            const size_t i0 = r * 8;
+            float a[8], b[8];
+            if (i0 + 8 <= p.n) {
+                const cf4 a0 = ((const cf4*)p.reA)[i0 / 4], a1 = ((const cf4*)p.reA)[i0 / 4 + 1];
+                const cf4 b0 = ((const cf4*)p.reB)[i0 / 4], b1 = ((const cf4*)p.reB)[i0 / 4 + 1];
+                a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+            } else {
+                for (int e = 0; e < 8; ++e) { a[e] = i0 + e < p.n ? p.reA[i0 + e] : 0.f; b[e] = i0 + e < p.n ? p.reB[i0 + e] : 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = i0 + e < p.n && same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr);
+                if (!in) continue;
+                const double w = (double)weight_at(wr, i0 + e);
+                const double ya = (double)a[e] * (double)a[e], yb = (double)b[e] * (double)b[e];
+                acc[0] += w; acc[1] += w * ya;
+                acc[EMF_VALS] += w; acc[EMF_VALS + 1] += w * yb;
+                double va = ya * sc0, vb = yb * sc0;
+#pragma unroll
+                for (int k = 0; k < EMF_LEVELS; ++k) {
+                    acc[2 + k] += w * floor(va + 0.5);
+                    acc[EMF_VALS + 2 + k] += w * floor(vb + 0.5);
+                    va *= 0.5; vb *= 0.5;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * EMF_VALS; ++i) q.red[i] = acc[i];
+    });
+    ex.template block_sum<2 * EMF_VALS>(st, [&](const double* tot) {
+        double* o = p.partials + (size_t)ex.bid() * (2 * EMF_VALS);
+        for (int i = 0; i < 2 * EMF_VALS; ++i) o[i] = tot[i];
+    });
+}
+// torch.norm / exact norm of a gathered class vector of `cnt` elements from its sampled statistics v[EMF_VALS]
+SM_HD double emf_norm_ratio(const double* v, int elo, double cnt) {
+    const double cnt_s = v[0], s_s = v[1];
+    const double N = floor(cnt / 8.0);
+    if (!(cnt_s > 0) || !(s_s > 0) || !(N >= 1)) return 1.0;
+    const double mean_y = s_s / cnt_s;
+    unsigned long long mb; memcpy(&mb, &mean_y, 8);
+    int e = (int)((mb >> 52) & 0x7ffu) - 1023 - 2;
+    double S = 0.0, left = N;
+    for (int guard = 0; guard < 400 && left > 0; ++guard) {
+        const double hi = emf_pow2(e + 1);
+        if (S >= hi) { ++e; continue; }
+        const int k = e - elo;
+        double g = (k >= 0 && k < EMF_LEVELS) ? v[2 + k] * emf_pow2(e - 23) / cnt_s : mean_y;
+        if (!(g > 0)) break;                     // every square rounds to nothing: the sum stalls here
+        const double need = (hi - S) / g;
+        if (need >= left) { S += left * g; left = 0; }
+        else { S = hi; left -= need; ++e; }
+    }
+    const double r = S / (N * mean_y);
+    return r > 0 ? sqrt(r) : 1.0;
+}
 
 // one work-group: sum the partials (fixed order per thread, then the block
 // reduction) and derive the constants (reference functions.py:36-43 on the
 // gathered slerp-class vectors)
+struct SlerpConstsState { double red[2 * EMF_VALS]; };
 template <class Ex>
 SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
-    typename Ex::template State<EmptyState> st;
+    typename Ex::template State<SlerpConstsState> st;
     ex.init(st);
     const int nt = ex.nthreads();
     const bool use_fb = p.overflow && *p.overflow;
     const double* src = use_fb ? p.fallback : p.partials;
     const int nsrc = use_fb ? p.nfallback : p.nparts;
-    ex.each(st, [&](int tid, EmptyState& s) {
+    double* emf_tot = (double*)(ex.lds() + 2 * LDS_SCRATCH_FLOATS);       // [2 * EMF_VALS] (the 36-value block sum's scratch
+                                                                          // runs past LDS_SCRATCH_FLOATS)
+    if (p.emf_part) {
+        ex.each(st, [&](int tid, SlerpConstsState& s) {
+            double a[2 * EMF_VALS];
+#pragma unroll
+            for (int q = 0; q < 2 * EMF_VALS; ++q) a[q] = 0.0;
+            for (int i = tid; i < p.emf_nparts; i += nt) {
+#pragma unroll
+                for (int q = 0; q < 2 * EMF_VALS; ++q) a[q] += p.emf_part[(size_t)i * (2 * EMF_VALS) + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * EMF_VALS; ++q) s.red[q] = a[q];
+        });
+        ex.template block_sum<2 * EMF_VALS>(st, [&](const double* tot) {
+            for (int q = 0; q < 2 * EMF_VALS; ++q) emf_tot[q] = tot[q];
+        });
+    }
+    ex.each(st, [&](int tid, SlerpConstsState& s) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
         for (int i = tid; i < nsrc; i += nt) {
             a0 += src[4 * i]; a1 += src[4 * i + 1];
@@ -2269,10 +2400,16 @@ SM_HD void k_slerp_consts(Ex& ex, const SlerpConstParams& p) {
         c.thr = p.thr ? *p.thr : 0.f;
         c.s00 = s00; c.s01 = s01; c.s11 = s11; c.n_slerp = (unsigned long long)cnt;
         double n0 = sqrt(s00), n1 = sqrt(s11), rel_bias = 1.0;
-        if (p.ref_norms && s00 > 0 && s11 > 0) {
+        if (s00 > 0 && s11 > 0) {
             // the reference's cosine divides by ITS norms; F.normalize's norm of (v1 - dot v0) carries about v1's bias
-            rel_bias = (double)p.ref_norms[1] / n1;
-            n0 = (double)p.ref_norms[0]; n1 = (double)p.ref_norms[1];
+            if (p.ref_norms) {
+                rel_bias = (double)p.ref_norms[1] / n1;
+                n0 = (double)p.ref_norms[0]; n1 = (double)p.ref_norms[1];
+            } else if (p.emf_part) {
+                rel_bias = emf_norm_ratio(emf_tot + EMF_VALS, p.emf_elo, cnt);
+                n0 *= emf_norm_ratio(emf_tot, p.emf_elo, cnt);
+                n1 *= rel_bias;
+            }
         }
         double dot = s01 / (n0 * n1);
         if (dot > 1.0) dot = 1.0;

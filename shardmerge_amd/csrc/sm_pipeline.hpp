@@ -150,6 +150,7 @@ SM_KERNEL_TAG(KSelect3, Select3Params, "select_lvl3_cand", k_select3(ex, p))
 SM_KERNEL_TAG(KReduceCand, ReduceCandParams, "slerp_reduce_cand", k_reduce_cand(ex, p))
 SM_KERNEL_TAG(KReduce, ReduceParams, "slerp_reduce", k_reduce(ex, p))
 SM_KERNEL_TAG(KSlerpConsts, SlerpConstParams, "slerp_consts", k_slerp_consts(ex, p))
+SM_KERNEL_TAG_LB(KClassEmf, ClassEmfParams, "class_norm_stats", k_class_emf(ex, p), 256, 2)
 SM_KERNEL_TAG(KSumPartials, SumPartialsParams, "sum_partials", k_sum_partials(ex, p))
 SM_KERNEL_TAG(KDeltaNorms, DeltaNormsParams, "delta_norms", k_delta_norms(ex, p))
 SM_KERNEL_TAG(KSumPartialsN, SumNParams, "sum_partials", k_sum_partials_n(ex, p))
@@ -185,7 +186,7 @@ SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finis
 // change to the host orchestration does not recompile a single kernel.
 #define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
 #define SM_SIDE_KERNELS_1(X) X(KF2R1) X(KI1R1) X(KPublish) X(KHist) X(KScan) X(KSelect2) X(KSelect2Cull) X(KBlendSel) \
-    X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials)
+    X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials) X(KClassEmf)
 #define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
     X(KCull) X(KAddition) X(KCorrPartial) X(KCorrFinish) X(KSerialNorm) X(KSpecNorm) X(KSumsqCand) X(KSumSpec)       \
     X(KSpecRescale) X(KDftp) X(KDftpPairs) X(KTranspose)
@@ -296,7 +297,7 @@ class Pipeline {
     explicit Pipeline(int device) : be(device) {}
     ~Pipeline() {
         for (auto& kv : plans_) if (kv.second.dev.tw) be.free((void*)kv.second.dev.tw);
-        for (Buffer* b : {&cand_, &t1_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_, &aten_}) if (b->p) be.free(b->p);
+        for (Buffer* b : {&cand_, &t1_, &small_, &tmpA_, &tmpB_, &tmpC_, &fullS_, &saveR_, &saveI_, &aten_, &emf_}) if (b->p) be.free(b->p);
         for (Buffer& b : pool_) if (b.p) be.free(b.p);
         if (mail_) be.free_host(mail_);
         for (Buffer& b : inter_) if (b.p) be.free(b.p);
@@ -355,7 +356,7 @@ class Pipeline {
         return SMHIP_OK;
     }
     size_t workspace_bytes() const {
-        size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap + aten_.cap;
+        size_t t = cand_.cap + t1_.cap + small_.cap + tmpA_.cap + tmpB_.cap + tmpC_.cap + fullS_.cap + saveR_.cap + saveI_.cap + aten_.cap + emf_.cap;
         for (const Buffer& b : inter_) t += b.cap;
         for (const Buffer& b : rowspec_) t += b.cap;
         for (const Buffer& b : pool_) t += b.cap;
@@ -928,10 +929,11 @@ class Pipeline {
 
     // masked slerp sums + constants (reference functions.py:36-43 on the slerp class).
     // fused_parts > 0: the level-2 selection pass already left the sums in d_part().
-    void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts, const float* ref_norms = nullptr) {
+    void run_slerp_consts(const Geo& g, bool have_thr, float t, int fused_parts, const float* ref_norms = nullptr,
+                          const double* emf_part = nullptr, int emf_nparts = 0, int emf_elo = 0) {
         const size_t total = (size_t)g.Cb * g.R;
         SlerpConstParams c;
-        c.ref_norms = ref_norms;
+        c.ref_norms = ref_norms; c.emf_part = emf_part; c.emf_nparts = emf_nparts; c.emf_elo = emf_elo;
         c.fallback = nullptr; c.nfallback = 0; c.overflow = nullptr;
         c.thr = have_thr ? d_thr(0) : nullptr; c.t = t; c.out = d_consts();
         c.zero_u32 = nullptr; c.zero_u32_count = 0;
@@ -948,7 +950,7 @@ class Pipeline {
             be.template launch<KReduce>(grid, 256, LDS_SCRATCH_FLOATS * 4, r, stream);
             c.partials = r.partials; c.nparts = grid;
         }
-        be.template launch<KSlerpConsts>(1, 256, LDS_SCRATCH_FLOATS * 4, c, stream);
+        be.template launch<KSlerpConsts>(1, 256, (2 * LDS_SCRATCH_FLOATS + 4 * EMF_VALS + 8) * 4, c, stream);
     }
 
     // norm_grid (optional): the row pass also leaves the sum of squares of what it stores in
@@ -1081,9 +1083,13 @@ class Pipeline {
             if (have_cut)
                 run_select(g, plane(g, P_REA), plane(g, P_REB), pct_index(2 * nfull, cutoff_pct), level1_hist_done, d_thr(0),
                            true, &fused);
+            // norm_mode = reference_cpu: the reference's cosine is taken with torch.norm's (biased) values of the gathered
+            // class vectors (functions.py:36,40) - modelled from sampled statistics (k_class_emf); class_norms_mode 2
+            // (test hook) runs the ordered emulation of sm_aten_norm.hpp over the planes instead
             const float* class_norms = nullptr;
-            if (ref_mode_ && !g.full && class_norms_enabled) {
-                // the norms of the gathered class vectors as torch.norm returns them (functions.py:36,40)
+            const double* emf_part = nullptr;
+            int emf_nparts = 0, emf_elo = 0;
+            if (ref_mode_ && class_norms_mode == 2 && !g.full) {
                 AtenSrc cs[2];
                 for (int w = 0; w < 2; ++w) {
                     memset(&cs[w], 0, sizeof(AtenSrc));
@@ -1092,8 +1098,25 @@ class Pipeline {
                     cs[w].R = g.R; cs[w].C = g.Cw; cs[w].Cb = g.Cb; cs[w].n = (size_t)g.Cb * g.R;
                 }
                 if (run_aten_norms(cs, 2, false)) class_norms = d_aten_out();
+            } else if (ref_mode_ && class_norms_mode == 1) {
+                ClassEmfParams q;
+                q.reA = plane(g, P_REA); q.reB = plane(g, P_REB); q.thr = have_cut ? d_thr(0) : nullptr;
+                q.R = g.R; q.C = g.Cw; q.Cb = g.Cb; q.n = (size_t)g.Cb * g.R;
+                // a lane ends near (class share ~ 1/4) * (sum of Re^2 over the full spectrum ~ n / 2) / 8: the
+                // levels reach 4 binades above that and 11 below (further down the sum loses nothing)
+                q.elo = (int)std::floor(std::log2(0.03 * (double)nfull + 1.0)) - 11;
+                q.sample = 1;
+                while (q.sample < EMF_MAX_SAMPLE && q.n / (2 * (size_t)q.sample) >= EMF_MIN_SAMPLED) q.sample *= 2;
+                const size_t rows = (q.n + 7) / 8, npieces = (rows + 8 * (size_t)q.sample - 1) / (8 * (size_t)q.sample);
+                q.iters = (int)std::max<size_t>(1, std::min<size_t>(64, npieces / ((size_t)32 * 1024)));
+                const int grid = (int)std::max<size_t>(1, (npieces + (size_t)32 * q.iters - 1) / ((size_t)32 * q.iters));
+                if (!ensure(emf_, (size_t)grid * 2 * EMF_VALS * sizeof(double))) {
+                    q.partials = (double*)emf_.p;
+                    be.template launch<KClassEmf>(grid, 256, LDS_SCRATCH_FLOATS * 4 * 2, q, stream);
+                    emf_part = q.partials; emf_nparts = grid; emf_elo = q.elo;
+                }
             }
-            run_slerp_consts(g, have_cut, (float)t, fused, class_norms);
+            run_slerp_consts(g, have_cut, (float)t, fused, class_norms, emf_part, emf_nparts, emf_elo);
             const bool spec = cull_pct > 0 && spec_cull && !safe_select && !g.full && (size_t)g.Cb * g.R >= spec_min_bins;
             if (spec) run_blend_spec(g, (float)t_sum, sumsq_parts != nullptr, spec_slot);
             else run_blend(g, BLEND_SLERP, 1, (float)t, (float)t_sum, cull_pct > 0);
@@ -1392,9 +1415,12 @@ class Pipeline {
     uint32_t* d_aten_stats() { return (uint32_t*)((float*)aten_.p + ATEN_MAX_SIGS + ATEN_MAX_SIGS * 8); }
     static constexpr size_t ATEN_HEAD_BYTES = 4096;
     bool aten_serial = false;          // test hook: the old single-work-group serial chain (k_serial_norm) instead
-    bool class_norms_enabled = true;   // test hook: 0 = reference_cpu leaves the slerp class's norms exact
+    int class_norms_mode = 1;          // reference_cpu and the slerp class's norms: 1 = modelled from sampled statistics
+                                       // (k_class_emf), 2 = ordered emulation over the planes, 0 = left exact (test hooks)
     bool ref_mode_ = false;            // the current layer runs with norm_mode = reference_cpu
-    bool run_aten_norms(const AtenSrc* srcs, int nsig, bool to_mail) {
+    // walk_on: a side stream for the walker and the finish (forked off the caller's stream behind the summaries;
+    // the CALLER joins it): those two are chains of dependent steps on 8 work-groups per signal - latency, no load
+    bool run_aten_norms(const AtenSrc* srcs, int nsig, bool to_mail, void* walk_on = nullptr) {
         if (nsig < 1 || nsig > ATEN_MAX_SIGS) return false;
         size_t max_rows = 0;
         const int kind = srcs[0].kind;
@@ -1433,6 +1459,9 @@ class Pipeline {
             if (kind) be.template launch<KAtenPartC>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
             else be.template launch<KAtenPart>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
         }
+        void* const main_stream = stream;
+        struct StreamSwap { void*& s; void* keep; ~StreamSwap() { s = keep; } } swap_back{stream, main_stream};
+        if (walk_on) { be.fork(main_stream, walk_on); stream = walk_on; }
         AtenWalkParams w;
         w.nsig = nsig; w.nchunks = nchunks; w.rec = summaries ? rec : nullptr; w.grp = grp; w.epred = epred;
         w.lanes = d_aten_lanes(); w.stats = d_aten_stats();
@@ -1469,6 +1498,29 @@ class Pipeline {
         for (int i = 0; i < k; ++i) out[i] = (double)mail_->snorm[i];
         return true;
     }
+    // norm_mode = reference_cpu, the deltas' norms: the summaries are computed on the caller's stream, the walker (8
+    // work-groups per signal, ~200 us of dependent steps) runs on a side stream of the backend beside the row pass
+    // and is joined before anything reads its result.  false: not started (the caller takes the synchronous path)
+    void* aten_walk_pending_ = nullptr;
+    bool aten_overlap = true;
+    bool begin_delta_ref_norms(const std::vector<Slot>& stack, size_t n) {
+        const int k = (int)stack.size();
+        void* aux = aten_overlap && !aten_serial ? be.aux_stream() : nullptr;
+        if (!aux || k < 1 || k > ATEN_MAX_SIGS) return false;
+        AtenSrc srcs[ATEN_MAX_SIGS];
+        for (int i = 0; i < k; ++i) {
+            memset(&srcs[i], 0, sizeof(AtenSrc));
+            srcs[i].kind = 0; srcs[i].sig = stack[i].sig; srcs[i].n = n; srcs[i].C = -1;
+            if (!aligned16(srcs[i].sig.x) || !aligned16(srcs[i].sig.base)) return false;
+        }
+        aten_walk_pending_ = run_aten_norms(srcs, k, true, aux) ? aux : nullptr;
+        return aten_walk_pending_ != nullptr;
+    }
+    void end_delta_ref_norms() {
+        if (aten_walk_pending_) be.join(aten_walk_pending_, stream);
+        aten_walk_pending_ = nullptr;
+    }
+
     // test hook: walker statistics of the last run_aten_norms, summed over lanes: chunks composed from their
     // summaries / crossed with the help of the group summaries / walked cooperatively
     void aten_stats(int nsig, unsigned long long* out3) {
@@ -1617,14 +1669,18 @@ class Pipeline {
         std::vector<float> norms32(d.k);
         int f1_grid = -1;
         bool f1_ready = false;
+        bool ref_started = false;          // reference_cpu: the deltas' torch.norm emulation runs beside the row passes
         if (d.k == 2) {
-            if ((rc = run_f1(g, stack[0].sig, stack[1].sig, f1_grid))) return rc;
+            if (ref_norms) ref_started = begin_delta_ref_norms(stack, n);
+            rc = run_f1(g, stack[0].sig, stack[1].sig, f1_grid);
+            end_delta_ref_norms();
+            if (rc) return rc;
             double na, nb;
             read_norms(f1_grid, na, nb);
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
         } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(g.R / 2 + 8) * g.batch <= PART_DOUBLES &&
-                   rows_first(g, stack) == SMHIP_OK) {
+                   ((ref_started = ref_norms && begin_delta_ref_norms(stack, n)), rows_first(g, stack) == SMHIP_OK)) {
             // K >= 3: every delta's ROWS are transformed up front, one signal at a time (row pairs);
             // the norms come with it (no separate pass over the inputs), and whichever deltas the
             // pairing puts together only need their column passes afterwards
@@ -1642,7 +1698,10 @@ class Pipeline {
                 }
             }
         }
-        if (ref_norms) {
+        if (ref_started && d.k != 2) { end_delta_ref_norms(); be.sync(stream); }      // (K = 2: joined in front of read_norms' sync)
+        if (ref_started) {
+            for (int i = 0; i < d.k; ++i) stack[i].norm = (double)mail_->snorm[i];
+        } else if (ref_norms) {
             SigDesc sg[16];
             double nr[16];
             for (int i = 0; i < d.k; ++i) sg[i] = stack[i].sig;
@@ -2065,7 +2124,7 @@ class Pipeline {
     // profiling table lives in the backend
   private:
     std::map<int, HostPlan> plans_;
-    Buffer t1_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_, aten_;
+    Buffer t1_, small_, tmpA_, tmpB_, tmpC_, fullS_, saveR_, saveI_, cand_, aten_, emf_;
     std::vector<Buffer> pool_ = std::vector<Buffer>(4);
     std::vector<char> pool_busy_ = std::vector<char>(4, 1);
     int pidx_[4] = {0, 1, 2, 3};

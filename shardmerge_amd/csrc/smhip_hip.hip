@@ -34,6 +34,8 @@ struct HipBackend {
     bool trace_launches = getenv("SMHIP_TRACE_LAUNCHES") != nullptr;
     std::vector<ProfEntry> prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t aux = nullptr;            // side stream (norm_mode = reference_cpu: the norm emulation beside the row pass)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     explicit HipBackend(int dev) : device(dev) {
         check(hipSetDevice(dev), "hipSetDevice");
@@ -45,6 +47,27 @@ struct HipBackend {
     ~HipBackend() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux) (void)hipStreamDestroy(aux);
+    }
+    // a second stream of this context: work between fork(s, aux) and join(aux, s) runs beside what the caller's
+    // stream s does in between, and is complete (in stream order) for everything s does after the join
+    void* aux_stream() {
+        if (!aux && ok()) {
+            if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; (void)hipGetLastError(); return nullptr; }
+            check(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "hipEventCreate");
+            check(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming), "hipEventCreate");
+        }
+        return (void*)aux;
+    }
+    void fork(void* s, void* a) {
+        check(hipEventRecord(ev_fork, (hipStream_t)s), "hipEventRecord");
+        check(hipStreamWaitEvent((hipStream_t)a, ev_fork, 0), "hipStreamWaitEvent");
+    }
+    void join(void* a, void* s) {
+        check(hipEventRecord(ev_join, (hipStream_t)a), "hipEventRecord");
+        check(hipStreamWaitEvent((hipStream_t)s, ev_join, 0), "hipStreamWaitEvent");
     }
     void check(hipError_t e, const char* what) {
         if (e != hipSuccess && first_err == hipSuccess) {

@@ -58,6 +58,10 @@ struct HostBackend {
     void free_host(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n, void*) { ::memset(p, v, n); }
     void sync(void*) {}
+    // (a single sequential "stream": the side stream is the same one)
+    void* aux_stream() { static int token; return &token; }
+    void fork(void*, void*) {}
+    void join(void*, void*) {}
     void d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); }
     void h2d(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); }
     template <class K>

@@ -424,6 +424,104 @@ def test_norm_mode_reference_cpu_reproduces_torch_norm(engine):
         engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, norm_mode="fast")
 
 
+def test_reference_cpu_norm_is_torch_norm_bit_for_bit(engine):
+    """smhip_reference_cpu_norm (what norm_mode = reference_cpu takes every spatial norm with) against torch.norm on
+    the host, bit for bit: ATen's kernel is fma(x, x, acc) in 8 serial fp32 lanes, lanes added in order, the n % 8
+    tail (first 4 * (T / 4) elements as product + add, the rest as fma), sqrt - reproduced by a PARALLEL algorithm
+    (csrc/sm_aten_norm.hpp).  Sizes cover the one-chunk path, several chunks, the summaries' window; inputs cover
+    bf16 / f16 deltas (lattice values: ties everywhere), general fp32 (where a rounded product would differ from
+    the fma), every tail length, and data that defeats the binade predictions."""
+    import math
+    torch.manual_seed(0)
+
+    def check(x, b=None, what=""):
+        mine = engine.reference_cpu_norm(x, b)
+        ref = torch.norm(x.float() - (b.float() if b is not None else 0)).item()
+        assert mine == ref or (math.isnan(mine) and math.isnan(ref)), f"{what} n={x.numel()}: {mine!r} vs torch {ref!r}"
+
+    for n in (1, 5, 8, 9, 12, 13, 15, 1000, 4099, 4100, 4102, 65536, 3 * 65536 + 7, (1 << 20) + 5, 1 << 22):
+        check(torch.randn(n) * 0.003, what="gauss")
+        check(torch.randn(n) * 300.0, what="large")
+        for dt in (torch.bfloat16, torch.float16):
+            b = (torch.randn(n) * 0.02).to(dt)
+            check((b.float() + torch.randn(n) * 0.003).to(dt), b, what=str(dt))
+    n = 1 << 21
+    x = torch.randn(n) * 0.003
+    x[n // 2:] *= 100
+    check(x, what="step up")
+    x = torch.randn(n) * 0.003
+    x[::8] *= 50
+    check(x, what="one lane 50x larger")
+    x = torch.zeros(n)
+    x[n // 2:] = torch.randn(n // 2) * 0.01
+    check(x, what="zeros first")
+    check(torch.randn(n) * 1e-22, what="squares underflow")
+    check(torch.randn(n) * 1e19, what="overflow to inf")
+    check(torch.full((n,), 0.0078125), what="all ties")
+    check(torch.randn(n).abs() ** 8 * 1e-3, what="heavy tail")
+    x = torch.randn(n) * 0.003
+    x[777777] = float("nan")
+    check(x, what="nan")
+    # the walker composed most chunks from their summaries (this is not the serial chain in disguise)
+    engine.reference_cpu_norm(torch.randn(1 << 22) * 0.003)
+    assert engine.ctx.debug_query("aten_fast") > 400 and engine.ctx.debug_query("aten_slow") <= 16
+    # and the old serial single-work-group chain (test hook) agrees
+    engine.ctx.debug_option("aten_serial", 1)
+    try:
+        x = torch.randn(1 << 16) * 0.003
+        assert engine.reference_cpu_norm(x) == torch.norm(x).item()
+    finally:
+        engine.ctx.debug_option("aten_serial", 0)
+
+
+def test_reference_cpu_mode_follows_the_biased_norms_everywhere(engine):
+    """norm_mode = reference_cpu at a size where torch.norm's bias is visible (2048^2: -1e-5 on the slerp cosine):
+    the layer's cosine follows the AS-IS oracle's - with the class norms modelled from sampled statistics (default),
+    with the ordered emulation over the planes (test hook class_norms = 2) - and not the exact-norm oracle's, which
+    is what leaving the class norms exact (class_norms = 0) gives."""
+    from oracle import spectral_oracle as so
+    base, fts = so.synthetic_layer(2048, 2048, 2, seed=6048)
+    tr, trx = so.LayerTrace(), so.LayerTrace()
+    so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr)
+    with so.exact_norms():
+        so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    d_ref, d_exact = tr.steps[0].dot, trx.steps[0].dot
+    assert abs(d_ref - d_exact) > 5e-6                      # the effect under test exists at this size
+    got = {}
+    try:
+        for mode in (1, 2, 0):
+            engine.ctx.debug_option("class_norms", mode)
+            out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True, norm_mode="reference_cpu")
+            got[mode] = rep.infos[0].dot
+            assert rep.target_norm == tr.target_norm
+            assert so.rel_err(delta.cpu(), tr.merged_delta) < 3e-4
+    finally:
+        engine.ctx.debug_option("class_norms", 1)
+    assert abs(got[1] - d_ref) < 0.25 * abs(d_ref - d_exact), (got, d_ref, d_exact)
+    assert abs(got[2] - d_ref) < 0.25 * abs(d_ref - d_exact), (got, d_ref, d_exact)
+    assert abs(got[0] - d_exact) < 0.25 * abs(d_ref - d_exact), (got, d_ref, d_exact)
+
+
+def test_reference_cpu_mode_keeps_k3_intermediates_spectral(engine):
+    """K = 3 in norm_mode = reference_cpu: the intermediate stays in the spectral domain (its torch.norm is modelled
+    from its exact Parseval norm: aten_gauss_norm_ratio) and the layer still follows the as-is oracle's steps; with
+    the intermediates materialised (test hook) - whose norm is then emulated exactly - the result agrees."""
+    from oracle import spectral_oracle as so
+    base, fts = so.synthetic_layer(512, 1024, 3, seed=7103)
+    tr = so.LayerTrace()
+    so.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, trace=tr)
+    out_s, rep_s, delta_s = engine.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, want_delta=True, norm_mode="reference_cpu")
+    pc.check_layer_steps(rep_s, tr, out_s.numel())
+    engine.ctx.debug_option("spectral_intermediates", 0)
+    try:
+        out_m, rep_m, delta_m = engine.merge_layer(fts, [base] * 3, so.ALPHAS[:3], base, want_delta=True, norm_mode="reference_cpu")
+    finally:
+        engine.ctx.debug_option("spectral_intermediates", 1)
+    pc.check_layer_steps(rep_m, tr, out_m.numel())
+    assert rep_s.target_norm == rep_m.target_norm == tr.target_norm
+    assert so.rel_err(delta_s.cpu(), delta_m.cpu()) < 2e-2         # the K = 3 floor (DESIGN 6.2): both within it
+
+
 @pytest.mark.parametrize("k", [2, 3])
 def test_rank3_tensor_is_a_batch_of_transforms_with_global_statistics(engine, k):
     """The reference transforms the LAST TWO dims of an N-D tensor (fftn(dim=(-2,-1)),

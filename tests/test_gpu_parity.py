@@ -320,7 +320,10 @@ from tests import test_emul_parity as emul_tier      # noqa: E402  (functions ta
 _SHARED = [emul_tier.test_inf_raises_like_reference, emul_tier.test_nan_is_zeroed, emul_tier.test_heavy_ties,
            emul_tier.test_unsupported_length_is_loud, emul_tier.test_non_finite_delta_norm_is_an_error_not_a_hang,
            emul_tier.test_mixed_input_dtypes_are_promoted_not_demoted, emul_tier.test_nan_inf_policy_in_the_inverse_row_pass,
-           emul_tier.test_norm_mode_reference_cpu_reproduces_torch_norm]
+           emul_tier.test_norm_mode_reference_cpu_reproduces_torch_norm,
+           emul_tier.test_reference_cpu_norm_is_torch_norm_bit_for_bit,
+           emul_tier.test_reference_cpu_mode_follows_the_biased_norms_everywhere,
+           emul_tier.test_reference_cpu_mode_keeps_k3_intermediates_spectral]
 
 
 @pytest.mark.parametrize("check", _SHARED, ids=lambda f: f.__name__[5:])
@@ -392,11 +395,25 @@ def test_real_model_shapes_k2_vs_exact_norm_oracle(engine, shape):
     assert mism < 0.08, f"{mism:.3%} of the bf16 outputs differ"
 
 
+def _layer_ms(engine, fts, bases, alphas, base, norm_mode, reps=5):
+    """wall time per merge_layer call, single stream, workspace warm"""
+    import time
+    engine.merge_layer(fts, bases, alphas, base, norm_mode=norm_mode)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(reps):
+        engine.merge_layer(fts, bases, alphas, base, norm_mode=norm_mode)
+    torch.cuda.synchronize()
+    return (time.time() - t0) / reps * 1e3
+
+
 def test_fullsize_8192sq_vs_reference_as_is(engine):
     """One [8192 x 8192] K = 2 merge (the north-star micro-benchmark shape) against the oracle
     EXACTLY as the reference is - torch's CPU norm kernel included, which is biased by -5e-3 at
-    67 M elements (oracle/norm_bias_probe.py) - and against the exact-norm oracle.  The
-    measured errors are recorded (gpurun_out/parity_fullsize.json -> profiles/)."""
+    67 M elements (oracle/norm_bias_probe.py) - in norm_mode = reference_cpu (the mode bench.py
+    measures): BASELINE's 1e-3 on the bf16 output AND SURVEY 8(d)'s 1e-3 on the merged delta.
+    Also recorded: the accurate-norm mode against both oracles, and what the mode costs.
+    (gpurun_out/parity_fullsize.json -> profiles/)."""
     import json
     import os
     import time
@@ -410,25 +427,27 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     t_oracle = time.time() - t0
     out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
     out, delta = out.cpu(), delta.cpu()
-    t1 = time.time()
     out_r, rep_r, delta_r = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True, norm_mode="reference_cpu")
-    torch.cuda.synchronize()
-    t_refmode = time.time() - t1
     out_r, delta_r = out_r.cpu(), delta_r.cpu()
+    dev = [t.cuda() for t in fts], base.cuda()
+    ms_exact = _layer_ms(engine, dev[0], [dev[1]] * 2, so.ALPHAS[:2], dev[1], "exact")
+    ms_ref = _layer_ms(engine, dev[0], [dev[1]] * 2, so.ALPHAS[:2], dev[1], "reference_cpu")
     rec = {
         "shape": [8192, 8192], "k": 2, "seed": 1000, "oracle_seconds_both_modes": round(t_oracle, 1),
         "torch_threads": torch.get_num_threads(),
-        "as_is": {"out_rel_err": so.rel_err(out.float(), ref.float()), "delta_rel_err": so.rel_err(delta, tr.merged_delta),
-                  "target_norm_ref": tr.target_norm, "target_norm_hip": rep.target_norm},
         "as_is_with_norm_mode_reference_cpu": {
             "out_rel_err": so.rel_err(out_r.float(), ref.float()), "delta_rel_err": so.rel_err(delta_r, tr.merged_delta),
             "delta_beyond_64_tie_bins": pc.spectral_residual(delta_r, tr.merged_delta, drop=64)[1],
-            "target_norm_hip": rep_r.target_norm, "delta_norms_hip": rep_r.delta_norms, "layer_seconds": round(t_refmode, 3)},
-        "exact_norms": {"out_rel_err": so.rel_err(out.float(), refx.float()), "delta_rel_err": so.rel_err(delta, trx.merged_delta),
-                        "target_norm_ref": trx.target_norm},
+            "target_norm_hip": rep_r.target_norm, "target_norm_ref": tr.target_norm, "delta_norms_hip": rep_r.delta_norms,
+            "cosine_hip": rep_r.infos[0].dot, "cosine_ref": tr.steps[0].dot, "cosine_exact_norm_oracle": trx.steps[0].dot},
+        "as_is_with_exact_norms": {"out_rel_err": so.rel_err(out.float(), ref.float()), "delta_rel_err": so.rel_err(delta, tr.merged_delta),
+                                   "target_norm_hip": rep.target_norm},
+        "exact_norm_oracle_vs_exact_norms": {"out_rel_err": so.rel_err(out.float(), refx.float()),
+                                             "delta_rel_err": so.rel_err(delta, trx.merged_delta), "target_norm_ref": trx.target_norm},
         "reference_self_shift": {"out": so.rel_err(ref.float(), refx.float()),
                                  "delta": so.rel_err(tr.merged_delta, trx.merged_delta)},
-        "steps_hip": [vars(i) for i in rep.infos],
+        "layer_ms_single_stream": {"exact": round(ms_exact, 3), "reference_cpu": round(ms_ref, 3), "ratio": round(ms_ref / ms_exact, 3)},
+        "steps_hip_reference_cpu": [vars(i) for i in rep_r.infos],
         "steps_as_is": [{k: v for k, v in vars(b).items() if k != "culled_mask"} for b in tr.steps if b is not None],
         "steps_exact": [{k: v for k, v in vars(b).items() if k != "culled_mask"} for b in trx.steps if b is not None],
     }
@@ -436,17 +455,21 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "parity_fullsize.json"), "w") as fh:
         json.dump(rec, fh, indent=1)
-    print(json.dumps({k: rec[k] for k in ("as_is", "as_is_with_norm_mode_reference_cpu", "exact_norms", "reference_self_shift")}))
+    print(json.dumps({k: rec[k] for k in ("as_is_with_norm_mode_reference_cpu", "as_is_with_exact_norms",
+                                          "exact_norm_oracle_vs_exact_norms", "reference_self_shift", "layer_ms_single_stream")}))
+    # accurate norms against the accurate-norm oracle
     pc.check_layer_steps(rep, trx, out.numel())
-    assert rec["exact_norms"]["delta_rel_err"] < 1e-3 and rec["exact_norms"]["out_rel_err"] < 1e-3
-    # default (accurate norms) vs the reference as it is: what the norm artefact does to the reference itself
-    assert rec["as_is"]["delta_rel_err"] < 1e-3 + 1.5 * rec["reference_self_shift"]["delta"]
-    # norm_mode = reference_cpu: BASELINE's tolerance (1e-3 relative, bf16 output) against the
-    # reference's device="cpu" output AS IT IS, and the stricter delta-level bar of SURVEY 8(d)
-    pc.check_layer_steps(rep_r, tr, out.numel(), biased_slerp_norms=True)
+    assert rec["exact_norm_oracle_vs_exact_norms"]["delta_rel_err"] < 1e-3 and rec["exact_norm_oracle_vs_exact_norms"]["out_rel_err"] < 1e-3
+    # norm_mode = reference_cpu against the reference's device="cpu" output AS IT IS
+    pc.check_layer_steps(rep_r, tr, out.numel())
     assert rep_r.target_norm == tr.target_norm
+    assert rep_r.delta_norms == [float((f.float() - base.float()).norm()) for f in fts]       # torch.norm's values, bit for bit
+    assert abs(rep_r.infos[0].dot - tr.steps[0].dot) < 0.05 * abs(tr.steps[0].dot - trx.steps[0].dot)
     assert rec["as_is_with_norm_mode_reference_cpu"]["out_rel_err"] < 1e-3
-    assert rec["as_is_with_norm_mode_reference_cpu"]["delta_rel_err"] < 2e-3
+    assert rec["as_is_with_norm_mode_reference_cpu"]["delta_rel_err"] < 1e-3
+    assert rec["as_is_with_norm_mode_reference_cpu"]["delta_beyond_64_tie_bins"] < 2e-5
+    # what the conforming mode costs (single stream; bench.py's 8 streams hide the walker's latency)
+    assert ms_ref <= 1.4 * ms_exact, f"reference_cpu {ms_ref:.2f} ms vs exact {ms_exact:.2f} ms per layer"
 
 
 def test_llama3_70b_mlp_shape_fullsize_k2_vs_exact_norm_oracle(engine):
