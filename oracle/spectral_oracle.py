@@ -132,14 +132,37 @@ class BlendTrace:
     culled_mask: Optional[torch.Tensor] = None   # bool, full spectrum: bins zeroed by the cull
 
 
+# The reference takes its two order statistics with a full torch.sort (85 % of its run time).  SELECT_MODE =
+# "kthvalue" takes the SAME element with torch.kthvalue (a selection, 7x faster at 134 M values): test-side
+# shortcut for the full-size GPU parity tests, pinned equal to the sort on every golden case by
+# tests/test_oracle_golden.py.  The default restates the reference as it is.
+SELECT_MODE = "sort"
+
+
+class fast_select:
+    """Context manager: order statistics by selection instead of a full sort (same values)."""
+
+    def __enter__(self):
+        global SELECT_MODE
+        self._old = SELECT_MODE
+        SELECT_MODE = "kthvalue"
+
+    def __exit__(self, *exc):
+        global SELECT_MODE
+        SELECT_MODE = self._old
+
+
 def kth_smallest(values: torch.Tensor, fraction: float) -> float:
     """Order statistic the reference takes with a full sort
     (functions.py:114-119 and :139-141): element ``int(len*fraction)`` of the
     ascending sort, clamped to the last element."""
-    flat, _ = torch.sort(values.ravel(), descending=False)
+    flat = values.ravel()
     idx = int(len(flat) * fraction)
     if idx >= len(flat):
         idx = len(flat) - 1
+    if SELECT_MODE == "kthvalue":
+        return torch.kthvalue(flat, idx + 1).values.item()
+    flat, _ = torch.sort(flat, descending=False)
     return flat[idx].item()
 
 
@@ -183,8 +206,12 @@ def interpolate_fft_components(
     n_culled = 0
     kill = None
     if cull_pct > 0:
-        mag, _ = torch.sort(out.real.abs().ravel(), descending=False)
-        cull_thr = mag[int(len(mag) * cull_pct)].item()
+        if SELECT_MODE == "kthvalue":
+            mag = out.real.abs().ravel()
+            cull_thr = torch.kthvalue(mag, int(len(mag) * cull_pct) + 1).values.item()
+        else:
+            mag, _ = torch.sort(out.real.abs().ravel(), descending=False)
+            cull_thr = mag[int(len(mag) * cull_pct)].item()
         below = int((mag < cull_thr).sum())
         # functions.py:143 overflow guard (cannot fire on sorted data; kept)
         if not below > len(mag) * (cull_pct * 2):

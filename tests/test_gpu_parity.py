@@ -378,7 +378,7 @@ def test_real_model_shapes_k2_vs_exact_norm_oracle(engine, shape):
     rows, cols = shape
     base, fts = so.synthetic_layer(rows, cols, 2, seed=900 + rows + cols)
     trx = so.LayerTrace()
-    with so.exact_norms():
+    with so.exact_norms(), so.fast_select():
         refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
     out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
     pc.check_layer_steps(rep, trx, out.numel())
@@ -421,9 +421,10 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     base, fts = so.synthetic_layer(8192, 8192, 2, seed=1000)
     t0 = time.time()
     tr, trx = so.LayerTrace(), so.LayerTrace()
-    ref = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr)
-    with so.exact_norms():
-        refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    with so.fast_select():
+        ref = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=tr)
+        with so.exact_norms():
+            refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
     t_oracle = time.time() - t0
     out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
     out, delta = out.cpu(), delta.cpu()
@@ -472,39 +473,89 @@ def test_fullsize_8192sq_vs_reference_as_is(engine):
     assert ms_ref <= 1.4 * ms_exact, f"reference_cpu {ms_ref:.2f} ms vs exact {ms_exact:.2f} ms per layer"
 
 
-def test_llama3_70b_mlp_shape_fullsize_k2_vs_exact_norm_oracle(engine):
-    """[28672 x 8192] - the tensor shape that holds 82 % of a Llama-3-70B block's parameters, the folded
-    column pass, the speculative cull selection - at FULL size against the exact-norm oracle (~90 s of
-    host work).  235 M elements have 64 ... 256 bins within rounding of a threshold: the
-    residual is taken beyond the 256 largest bins of the difference's spectrum; measured 4.2e-7.
-    Recorded in gpurun_out/parity_fullsize_70b_mlp.json -> profiles/."""
+def _fullsize_as_is(engine, rows, cols, k, seed, tag, masked=True):
+    """One layer of a BASELINE shape at FULL size in norm_mode = reference_cpu (the mode bench.py measures) against
+    the oracle AS THE REFERENCE IS (torch's CPU norms included; order statistics by selection instead of a full
+    sort: so.fast_select(), pinned equal by tests/test_oracle_golden.py).  Records gpurun_out/<tag>.json
+    (-> profiles/) and returns the record."""
     import json
     import os
     import time
     _oracle_threads()
-    rows, cols = 28672, 8192
-    base, fts = so.synthetic_layer(rows, cols, 2, seed=4242)
+    base, fts = so.synthetic_layer(rows, cols, k, seed=seed)
     t0 = time.time()
-    trx = so.LayerTrace()
-    with so.exact_norms():
-        refx = so.merge_layer(fts, [base, base], so.ALPHAS[:2], base, trace=trx)
+    tr = so.LayerTrace()
+    with so.fast_select():
+        ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
     t_oracle = time.time() - t0
-    out, rep, delta = engine.merge_layer(fts, [base, base], so.ALPHAS[:2], base, want_delta=True)
+    out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True, norm_mode="reference_cpu")
     out, delta = out.cpu(), delta.cpu()
-    pc.check_layer_steps(rep, trx, out.numel())
-    resid = {drop: pc.spectral_residual(delta, trx.merged_delta, drop=drop) for drop in (64, 256)}
-    rec = {"shape": [rows, cols], "k": 2, "seed": 4242, "oracle_seconds": round(t_oracle, 1),
-           "delta_rel_err": resid[64][0], "delta_beyond_64_tie_bins": resid[64][1], "delta_beyond_256_tie_bins": resid[256][1],
-           "out_rel_err": so.rel_err(out.float(), refx.float()),
-           "bf16_outputs_that_differ": (out.view(torch.int16) != refx.view(torch.int16)).float().mean().item(),
+    assert rep.delta_norms == [float((f.float() - base.float()).norm()) for f in fts]        # torch.norm's values, bit for bit
+    assert rep.target_norm == tr.target_norm
+    pc.check_layer_steps(rep, tr, out.numel())
+    rec = {"shape": [rows, cols], "k": k, "seed": seed, "norm_mode": "reference_cpu", "oracle": "as the reference is (torch CPU norms)",
+           "oracle_seconds": round(t_oracle, 1), "torch_threads": torch.get_num_threads(),
+           "out_rel_err": so.rel_err(out.float(), ref.float()), "delta_rel_err": so.rel_err(delta, tr.merged_delta),
+           "bf16_outputs_that_differ": (out.view(torch.int16) != ref.view(torch.int16)).float().mean().item(),
+           "target_norm": rep.target_norm, "delta_norms": rep.delta_norms, "branches": rep.branches,
            "steps_hip": [vars(i) for i in rep.infos],
-           "steps_exact": [{k: v for k, v in vars(b).items() if k != "culled_mask"} for b in trx.steps if b is not None]}
+           "steps_as_is": [({kk: v for kk, v in vars(b).items() if kk != "culled_mask"} if b is not None else None) for b in tr.steps]}
+    if k == 2:
+        for drop in (64, 256):
+            rec[f"delta_beyond_{drop}_tie_bins"] = pc.spectral_residual(delta, tr.merged_delta, drop=drop)[1]
+    elif masked:
+        outside, inside, flips = pc.masked_spectral_check(delta, tr)
+        rec.update({"delta_outside_culled_bins": outside, "delta_inside_culled_bins": inside, "final_cull_flips": flips})
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "parity_fullsize_70b_mlp.json"), "w") as fh:
+    with open(os.path.join(d, tag + ".json"), "w") as fh:
         json.dump(rec, fh, indent=1)
-    assert rec["delta_beyond_256_tie_bins"] < 5e-6, rec
+    print(json.dumps({kk: rec[kk] for kk in rec if not kk.startswith("steps")}))
+    return rec
+
+
+def test_llama3_70b_mlp_shape_fullsize_k2_as_is(engine):
+    """[28672 x 8192] - the tensor shape that holds 82 % of a Llama-3-70B block's parameters (folded column pass,
+    speculative cull selection), K = 2, against the reference as it is: BASELINE's 1e-3 on the bf16 output and
+    SURVEY 8(d)'s 1e-3 on the merged delta.  235 M elements have 64 ... 256 bins within rounding of a threshold
+    (DESIGN 6.1): the residual is taken beyond the 256 largest bins of the difference's spectrum."""
+    rec = _fullsize_as_is(engine, 28672, 8192, 2, 4242, "parity_fullsize_70b_mlp")
+    assert rec["delta_beyond_256_tie_bins"] < 2e-5, rec
     assert rec["delta_rel_err"] < 1e-3 and rec["out_rel_err"] < 1e-3 and rec["bf16_outputs_that_differ"] < 0.08, rec
+
+
+def test_llama3_70b_mlp_down_shape_fullsize_k2_as_is(engine):
+    """[8192 x 28672] (down_proj: the 28672-point ROW plans), K = 2, against the reference as it is."""
+    rec = _fullsize_as_is(engine, 8192, 28672, 2, 4343, "parity_fullsize_70b_mlp_down")
+    assert rec["delta_beyond_256_tie_bins"] < 2e-5, rec
+    assert rec["delta_rel_err"] < 1e-3 and rec["out_rel_err"] < 1e-3 and rec["bf16_outputs_that_differ"] < 0.08, rec
+
+
+def test_8192sq_fullsize_k3_as_is(engine):
+    """[8192 x 8192], K = 3 (the metric's K): spectral intermediate, modelled norm of the intermediate, two rounds.
+    Round 2 decides on rounding noise in the reference itself (it moves by 1.6e-3 on the bf16 output
+    when its own FFT is evaluated in fp64): everything reproducible is compared step by step and outside the bins
+    round 1 culled; the total is held to 3x that floor."""
+    rec = _fullsize_as_is(engine, 8192, 8192, 3, 5151, "parity_fullsize_8192sq_k3")
+    assert rec["branches"].count("slerp") == 2
+    assert rec["out_rel_err"] < 5e-3, rec
+    assert rec["delta_outside_culled_bins"] < 1e-3, rec
+
+
+def test_llama3_8b_mlp_shape_fullsize_k4_as_is(engine):
+    """[14336 x 4096] (Llama-3-8B / Mixtral MLP), K = 4 - BASELINE config 3: three pair merges, the last one of two
+    intermediates.  The reference's own K = 4 floor is 3.1e-2 on the bf16 output."""
+    rec = _fullsize_as_is(engine, 14336, 4096, 4, 6161, "parity_fullsize_8b_mlp_k4")
+    assert rec["branches"].count("slerp") == 3
+    assert rec["out_rel_err"] < 8e-2, rec
+    assert rec["delta_outside_culled_bins"] < pc.OUTSIDE_CULLED_TOL, rec     # (measured 1.7e-3: two rounds of culled bins feed the last merge)
+
+
+def test_llama3_70b_mlp_shape_fullsize_k3_as_is(engine):
+    """[28672 x 8192], K = 3 - the metric's configuration on its dominant tensor: steps checked, totals recorded."""
+    rec = _fullsize_as_is(engine, 28672, 8192, 3, 7171, "parity_fullsize_70b_mlp_k3", masked=False)
+    assert rec["branches"].count("slerp") == 2
+    assert rec["out_rel_err"] < 5e-3, rec
 
 
 # ---- N3 / N4 on the device ------------------------------------------------------------------------
