@@ -188,6 +188,7 @@ int smhip_reference_cpu_norm(smhip_ctx* ctx, const void* x, const void* base, in
  *      keeping it in the spectral domain (default 1). ----------------------------------- */
 int smhip_debug_option(smhip_ctx* ctx, const char* key, long value);
 /* test hook, read side: "spec_hit" = 1 if the last speculative blend's guess was confirmed, 0 if it was voided;
+ * "spec_checked" / "spec_hits": how many speculations this context has checked / confirmed since it was created;
  * "aten_fast" / "aten_group" / "aten_slow": chunks the last smhip_reference_cpu_norm composed from their summaries /
  * crossed with the group summaries / walked cooperatively
  * ("aten_serial" = 1 as an option selects the old serial single-work-group chain instead) */

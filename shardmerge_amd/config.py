@@ -15,8 +15,8 @@ reference's shard/config.py:24-126, so existing config files work unchanged.
       t_sum: 1.0
       target_norm_offset: 1.0e-10
       b: 0.1                    # merge_tensors_fft2_slerp's linear-blend threshold (functions.py:164)
-      norm_mode: exact          # exact (accurate norms: the reference's device="cuda" numerics) | reference_cpu
-                                # (torch's biased CPU norm kernel emulated: the reference's device="cpu" output)
+      norm_mode: reference_cpu  # reference_cpu (default: every norm as torch's CPU kernel returns it - the reference's
+                                # device="cpu" output) | exact (accurate norms: the reference's device="cuda" numerics)
       operator: fourier         # fourier (default: what the reference CLI hard-wires, __main__.py:22,67)
                                 # | addition | task_addition (shard/merge/addition.py, taskaddition.py)
 """
@@ -69,7 +69,7 @@ class MergeConfig:
     storage_dir: str = "storage"
     merge_options: Dict[str, float] = field(default_factory=dict)
     operator: str = "fourier"
-    norm_mode: str = "exact"
+    norm_mode: str = "reference_cpu"
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -130,7 +130,7 @@ class MergeConfig:
             raise click.BadParameter("finetune_merge must be a list of model URIs")
         raw["finetune_merge"] = [MergeModel(**entry) for entry in raw["finetune_merge"]]
         opts = dict(raw.get("merge_options") or {})
-        norm_mode = opts.pop("norm_mode", "exact")
+        norm_mode = opts.pop("norm_mode", "reference_cpu")
         if norm_mode not in ("exact", "reference_cpu"):
             raise click.BadParameter("merge_options.norm_mode must be 'exact' or 'reference_cpu'")
         raw["norm_mode"] = norm_mode

@@ -1912,6 +1912,7 @@ SM_HD void k_spec_check(Ex& ex, const SpecCheckParams& p) {
             const uint32_t hit = (g == res[0] + 1u) ? 1u : 0u;
             res[3] = hit;
             *p.flag = hit;
+            p.flag[1] += 1u; p.flag[2] += hit;               // running totals: speculations checked / confirmed
             *p.guess = res[0] + 1u;
             if (hit) {
                 p.sel->prefix = res[0]; p.sel->level = 1;

@@ -919,6 +919,12 @@ class Pipeline {
         be.sync(stream);
         return (long)v;
     }
+    // speculations checked / confirmed on this context since it was created (bench.py reports the hit rate)
+    void spec_totals(unsigned long long* checked, unsigned long long* hits) {
+        uint32_t v[3] = {0, 0, 0};
+        if (small_.p) { be.d2h(v, d_spec_flag(), sizeof v, stream); be.sync(stream); }
+        *checked = v[1]; *hits = v[2];
+    }
     // steps per thread of the cull's selection pass (and of the speculative blend in front of it)
     int cull_select_chunks(size_t total) const {
         int chunks = debug_sel_chunks ? (int)debug_sel_chunks : pick_chunks((total + 3) / 4, 256, 8, sel_wgs_per_cu);

@@ -7,18 +7,34 @@ one rank reads it from disk and ONE RCCL broadcast hands its payload to every
 rank over xGMI (`torch.distributed` backend "nccl" is RCCL on ROCm); each rank
 then merges the tensors it owns, reading only its own finetune tensors.
 
-Output: every rank writes the tensors it merged of a shard into a part file;
-after a barrier, shard `i` is assembled (CPU file I/O) by rank `i % world`, in
-layer order, exactly as the single-process writer would have written it.
+Nothing else travels between ranks:
+
+* the broadcasts are issued ahead, asynchronously, in shard order, up to
+  ``SHARDMERGE_BCAST_WINDOW`` shards (default 3) in front of the shard a rank
+  is merging - a rank waits for a shard's payload only when it gets there, so
+  ranks are not in lock-step (a shard holds a handful of tensors of very
+  different sizes: per shard no assignment is balanced, over a few it is);
+* the plan hands out tensors in shard order to the rank with the least work so
+  far (cost = estimated milliseconds per shape from measured kernel times), so
+  every PREFIX of the model is balanced and the ranks stay within the window;
+* every rank writes its own results: the output shard is a pre-sized
+  safetensors file (header from the plan) and a rank's tensors go to their
+  offsets with positional writes - no result ever crosses to a "writer rank".
+  The rank that completes a shard (a counter in the process group's store)
+  renames it into place; resume sees only complete shards.
 """
 from __future__ import annotations
 
 import asyncio
+import hashlib
 import json
 import logging
 import os
+import queue
+import threading
+import time
 from pathlib import Path
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -26,7 +42,7 @@ from .config import MergeConfig
 from .constants import INPUT_LAYER, OUTPUT_LAYER
 from .index import LocalModelIndex
 from .merge.fast_fourier import FourierMerge
-from .writer import ModelWriter, ShardLayer
+from .writer import ShardLayer
 
 logger = logging.getLogger(__name__)
 
@@ -56,10 +72,41 @@ def alg_bytes(numel: int, k: int) -> int:
     return numel * (60 * raw_pairs + 62 * (k - 1 - raw_pairs))
 
 
-def partition_lpt(costs: List[int], world: int) -> List[int]:
+# per-layer time on MI355X: a fixed part (launches; more of them per pair merge) plus a streaming part at the
+# pipeline's measured rate, slower where a length needs the long 28672-point plans (profiles/r02_kprof_final.txt,
+# r03: 28672x8192 K=3 5.8 ms, 8192^2 K=3 1.83 / K=2 1.2, 1024x8192 K=3 0.56, 1-D K=3 0.2)
+def est_ms(shape: Sequence[int], k: int) -> float:
+    """Estimated milliseconds to merge one block tensor of `shape` with k finetunes (the plan's cost)."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    if k <= 1:
+        return 0.02 + 8.0 * numel / 4.0e9
+    pairs = k - 1
+    if len(shape) < 2 or min(int(d) for d in shape[-2:]) == 1:
+        return 0.1 * pairs
+    rate = 5.0e9 if max(int(d) for d in shape[-2:]) <= 16384 else 4.2e9        # canonical bytes per millisecond
+    return 0.15 + 0.2 * pairs + alg_bytes(numel, k) / rate
+
+
+def partition_lpt(costs: List[float], world: int) -> List[int]:
     """Longest-processing-time-first assignment; deterministic (ties by index)."""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
-    load = [0] * world
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+def partition_in_order(costs: List[float], groups: List[int], world: int) -> List[int]:
+    """List scheduling in GROUP (shard) order: groups in ascending order, inside a group the largest first,
+    each to the rank with the least work so far.  Balanced over every prefix of the groups (within one
+    largest item), which is what lets the ranks run a bounded number of shards apart."""
+    order = sorted(range(len(costs)), key=lambda i: (groups[i], -costs[i], i))
+    load = [0.0] * world
     owner = [0] * len(costs)
     for i in order:
         r = min(range(world), key=lambda q: (load[q], q))
@@ -83,6 +130,8 @@ def _tensor_meta(index: LocalModelIndex, uri: str, shard_file: str) -> Dict[str,
 
 
 _ST_DTYPES = {"BF16": torch.bfloat16, "F16": torch.float16, "F32": torch.float32}
+_ST_NAMES = {torch.bfloat16: "BF16", torch.float16: "F16", torch.float32: "F32", torch.float64: "F64"}
+_ST_SIZE = {"BF16": 2, "F16": 2, "F32": 4, "F64": 8}
 
 
 def init_process_group(device: torch.device):
@@ -90,30 +139,137 @@ def init_process_group(device: torch.device):
     if dist.is_initialized():
         return dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if device.type == "cuda":
+    # one rank per GPU over RCCL.  (Rehearsal on a one-GPU box: SHARDMERGE_DIST_BACKEND=gloo lets several ranks share the
+    # card - RCCL refuses two ranks on one device; the base shards then travel through host memory.)
+    backend = os.environ.get("SHARDMERGE_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
+    if backend == "nccl":
         dist.init_process_group("nccl", device_id=device)
     else:
-        dist.init_process_group("gloo")
+        dist.init_process_group(backend)
     return dist
 
 
-def _shard_complete(path: Path, expected) -> bool:
-    """An output shard that exists with exactly the expected tensors (written atomically)."""
-    if not path.exists():
-        return False
+# ---- output shards written in place ------------------------------------------------------------------------
+def shard_header(entries: Sequence[Tuple[str, str, Sequence[int]]], metadata: Dict[str, str]) -> Tuple[bytes, Dict[str, Tuple[int, int]]]:
+    """The bytes in front of a safetensors payload (8-byte length + JSON padded to 8 bytes) for tensors
+    (name, dtype string, shape), laid out as safetensors' own writer does it (by dtype, widest first, then by
+    name - tests/test_host_logic.py pins the bytes against safetensors.torch.save_file), and the payload
+    offsets (begin, end) per name."""
+    rank_of_dtype = {"F64": 0, "F32": 1, "BF16": 2, "F16": 2}
+    order = sorted(entries, key=lambda e: (rank_of_dtype.get(e[1], 9), e[0]))
+    doc: Dict[str, object] = {"__metadata__": dict(metadata)}
+    offsets, pos = {}, 0
+    for name, dt, shape in order:
+        n = _ST_SIZE[dt]
+        for d in shape:
+            n *= int(d)
+        doc[name] = {"dtype": dt, "shape": [int(d) for d in shape], "data_offsets": [pos, pos + n]}
+        offsets[name] = (pos, pos + n)
+        pos += n
+    blob = json.dumps(doc, separators=(",", ":")).encode()
+    blob += b" " * ((8 - len(blob) % 8) % 8)
+    return len(blob).to_bytes(8, "little") + blob, offsets
+
+
+def _read_metadata(path: Path):
     try:
         with open(path, "rb") as fh:
             n = int.from_bytes(fh.read(8), "little")
             header = json.loads(fh.read(n))
     except Exception:
+        return None, None
+    return header.get("__metadata__", {}), {k for k in header if k != "__metadata__"}
+
+
+def _shard_complete(path: Path, expected, stamp: Optional[str] = None) -> bool:
+    """An output shard that exists with exactly the expected tensors (shards appear by an atomic rename) and,
+    when a stamp is given, was written by a run with the same models and options."""
+    if not path.exists():
         return False
-    return {k for k in header if k != "__metadata__"} == set(expected)
+    meta, names = _read_metadata(path)
+    if names is None or names != set(expected):
+        return False
+    return stamp is None or meta.get("shardmerge_config") == stamp
+
+
+def config_stamp(config: MergeConfig) -> str:
+    """What decides a shard's content: models, layer windows, weights, flags, operator, options, output dtype."""
+    from dataclasses import asdict
+    doc = {"output_base_model": config.output_base_model, "output_dtype": config.output_dtype,
+           "finetune_merge": [asdict(m) for m in config.finetune_merge],
+           "merge_options": dict(sorted((config.merge_options or {}).items())),
+           "operator": getattr(config, "operator", "fourier"), "norm_mode": getattr(config, "norm_mode", "exact")}
+    return hashlib.sha256(json.dumps(doc, sort_keys=True, default=str).encode()).hexdigest()[:16]
+
+
+class _InPlaceShardWriter:
+    """This rank's side of the output: results are copied to pinned memory asynchronously and a thread writes
+    them at their offsets of the pre-sized shard files (`.tmp-<shard>`, created by rank 0 from the plan)."""
+
+    def __init__(self, out_dir: Path, plans: Dict[str, dict], astype: torch.dtype, on_gpu: bool, on_written):
+        self.out_dir, self.plans, self.astype, self.on_gpu = out_dir, plans, astype, on_gpu
+        self.on_written = on_written                 # (shard) -> None, after each tensor of it is on disk
+        self.fds: Dict[str, int] = {}
+        self.jobs: "queue.Queue" = queue.Queue(maxsize=8)
+        self.error: Optional[BaseException] = None
+        self.thread = threading.Thread(target=self._run, name="shardmerge-writer", daemon=True)
+        self.thread.start()
+
+    def add(self, shard: str, name: str, tensor: torch.Tensor):
+        if self.error is not None:
+            raise self.error
+        plan = self.plans[shard]
+        t = tensor.detach().to(self.astype).contiguous()
+        if list(t.shape) != list(plan["shapes"][name]):
+            raise ValueError(f"{name}: merged shape {list(t.shape)} but the output shard was laid out for {plan['shapes'][name]}")
+        ev = None
+        if t.device.type == "cuda":
+            host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(t.device))
+        else:
+            host = t.to("cpu")
+        self.jobs.put((shard, name, host, ev))
+
+    def _run(self):
+        while True:
+            job = self.jobs.get()
+            try:
+                if job is None:
+                    return
+                if self.error is not None:
+                    continue
+                shard, name, host, ev = job
+                if ev is not None:
+                    ev.synchronize()
+                plan = self.plans[shard]
+                if shard not in self.fds:
+                    self.fds[shard] = os.open(self.out_dir / f".tmp-{shard}", os.O_WRONLY)
+                view = memoryview(host.view(torch.uint8).reshape(-1).numpy()).cast("B")
+                pos, done = plan["data_start"] + plan["offsets"][name][0], 0
+                while done < len(view):
+                    done += os.pwrite(self.fds[shard], view[done:done + (1 << 30)], pos + done)
+                self.on_written(shard)
+            except BaseException as exc:       # surfaced by the next add() / close()
+                self.error = exc
+            finally:
+                self.jobs.task_done()
+
+    def close(self):
+        self.jobs.put(None)
+        self.thread.join()
+        for fd in self.fds.values():
+            os.fsync(fd)
+            os.close(fd)
+        if self.error is not None:
+            raise self.error
 
 
 class _BaseShardReader:
     """The root rank's side of the base-shard broadcast: the shard's block tensors are read with
     positional reads (4 threads) into ONE pinned buffer and go to the device with ONE copy; the
-    next shard this rank is root of is read in the background while the current one is merged."""
+    next shards this rank is root of are read in the background."""
 
     def __init__(self, index: LocalModelIndex, uri: str, pinned: bool):
         from concurrent.futures import ThreadPoolExecutor
@@ -134,7 +290,8 @@ class _BaseShardReader:
         return host
 
     def start(self, shard: str, layout, total: int):
-        import threading
+        if shard in self.pending:
+            return
         box = {}
 
         def run():
@@ -160,15 +317,11 @@ class _BaseShardReader:
 
 
 async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, device: str):
-    """One rank of the N-rank merge.  Per base shard, in file order:
-      1. the root (shard index mod N) reads the shard's block tensors and ONE broadcast (RCCL over
-         xGMI) hands them to every rank - the only collective of the data path, no reduction;
-      2. every rank merges the tensors the plan (LPT on algorithmic bytes) gave it; its finetune
-         tensors are prefetched (loader.py);
-      3. results leave for the shard's writer rank (= the root): its own through the asynchronous
-         pinned copy of ModelWriter, the other ranks' with one point-to-point message each (device
-         to device) - no part files, every tensor is written to disk once.
-    A shard whose output file is already complete is skipped by all ranks (resume)."""
+    """One rank of the N-rank merge (module docstring).  Per base shard, in file order, the root (shard index
+    mod N) reads the shard's block tensors and ONE broadcast (RCCL over xGMI) hands them to every rank - the
+    only collective of the data path, no reduction, issued asynchronously a few shards ahead; every rank merges
+    the tensors the plan gave it (its finetune tensors prefetched by loader.py) and writes them into the output
+    shard in place.  A shard whose output file is already complete is skipped by all ranks (resume)."""
     world, me = world_size(), rank()
     if ENGINE_FACTORY is not None:
         engine = ENGINE_FACTORY()
@@ -180,6 +333,10 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     on_gpu = dev.type == "cuda"
     use_dist = world > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1"
     dist = init_process_group(dev) if use_dist else None
+    store = None
+    if dist is not None:
+        from torch.distributed import distributed_c10d
+        store = distributed_c10d._get_default_store()
 
     from .merge import operator_class
     merger = operator_class(getattr(config, "operator", "fourier"))(config=config, index_manager=index, engine=engine)
@@ -192,43 +349,107 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
     shards = sorted(set(weight_map.values()))
     out_dir = config.output_path
     out_dir.mkdir(parents=True, exist_ok=True)
-    # leftovers of an earlier (crashed) run must never reach this run's shards
-    if me == 0:
-        for stale in list(out_dir.glob(".part-*")) + list(out_dir.glob(".tmp-*")):
-            stale.unlink()
-    if dist is not None:
-        dist.barrier()
+    stamp = config_stamp(config)
+    run_id = ""
 
-    # ---- plan: the same on every rank --------------------------------------------------
+    # ---- plan: made by rank 0, the same on every rank ---------------------------------------------
     metas = {s: _tensor_meta(index, base_uri, s) for s in shards}
     names_of = {s: sorted((n for n in weight_map if weight_map[n] == s), key=rank_of.get) for s in shards}
-    done = {s: _shard_complete(out_dir / s, names_of[s]) for s in shards}
-    names, costs = [], []
-    for s in shards:
+    if me == 0:
+        # leftovers of an earlier (crashed) run must never reach this run's shards
+        for stale in list(out_dir.glob(".part-*")) + list(out_dir.glob(".tmp-*")):
+            stale.unlink()
+        done_list = [_shard_complete(out_dir / s, names_of[s], stamp) for s in shards]
+        run_id = hashlib.sha256(f"{time.time_ns()}-{os.getpid()}".encode()).hexdigest()[:12]
+    else:
+        done_list = [False] * len(shards)
+    if dist is not None:
+        box = [done_list, run_id]
+        dist.broadcast_object_list(box, src=0)          # ONE decision (a rank scanning later would see other files)
+        done_list, run_id = box
+    done = dict(zip(shards, done_list))
+    todo = [s for s in shards if not done[s]]
+
+    # shapes of the outputs: block tensors have the base's, a passthrough tensor (embedding, final norm, lm_head)
+    # has its PROVIDER's - a finetune flagged is_input / is_output may bring an extended vocabulary
+    provider_meta: Dict[Tuple[str, str], Dict[str, tuple]] = {}
+
+    def out_shape(s: str, name: str) -> List[int]:
+        sl = ShardLayer(rank_of[name], s, name, False)
+        if fourier and sl.layer_number in (INPUT_LAYER, OUTPUT_LAYER):
+            uri = merger._layer_requests(sl)[0][0]
+            if uri != base_uri:
+                f = index.model_indexes[uri]["weight_map"][name]
+                if (uri, f) not in provider_meta:
+                    provider_meta[(uri, f)] = _tensor_meta(index, uri, f)
+                return list(provider_meta[(uri, f)][name][0])
+        return list(metas[s][name][0])
+
+    names, costs, groups = [], [], []
+    for si, s in enumerate(shards):
         if done[s]:
             continue
         for name in names_of[s]:
             number = ShardLayer(rank_of[name], s, name, False).layer_number
+            shape = out_shape(s, name)
             numel = 1
-            for d in metas[s][name][0]:
+            for d in shape:
                 numel *= d
             if number in (INPUT_LAYER, OUTPUT_LAYER) or not fourier:
-                cost = 2 * numel * (1 if fourier else len(config.finetune_merge) + 2)      # a copy / one streaming pass
+                cost = 0.02 + 2.0 * numel * (1 if fourier else len(config.finetune_merge) + 2) / 4.0e9   # a copy / one streaming pass
             else:
                 k = sum(1 for m in config.finetune_merge if m.use_layer_index(number))
-                cost = alg_bytes(numel, k)
+                cost = est_ms(shape, k)
             names.append((s, name))
             costs.append(cost)
-    owner = partition_lpt(costs, world)
+            groups.append(si)
+    owner = partition_in_order(costs, groups, world)
     owner_of = {names[i]: owner[i] for i in range(len(names))}
     mine = {key for key, o in owner_of.items() if o == me}
     logger.info(f"rank {me}/{world}: {len(mine)} of {len(names)} tensors, "
-                f"{sum(c for c, o in zip(costs, owner) if o == me) / 1e9:.2f} GB algorithmic traffic"
+                f"{sum(c for c, o in zip(costs, owner) if o == me):.1f} of {sum(costs):.1f} ms estimated"
                 + (f"; {sum(done.values())} shard(s) already complete" if any(done.values()) else ""))
+
+    # ---- output shards: laid out from the plan, created by rank 0, filled in place by every rank ----
+    astype_name = _ST_NAMES[config.output_astype]
+    plans: Dict[str, dict] = {}
+    for s in todo:
+        shapes = {n: out_shape(s, n) for n in names_of[s]}
+        head, offsets = shard_header([(n, astype_name, shapes[n]) for n in names_of[s]], {"format": "pt", "shardmerge_config": stamp})
+        plans[s] = {"head": head, "offsets": offsets, "data_start": len(head), "shapes": shapes,
+                    "size": len(head) + max((e for _, e in offsets.values()), default=0),
+                    "owners": sorted({owner_of[(s, n)] for n in names_of[s]})}
+    if me == 0:
+        for s in todo:
+            with open(out_dir / f".tmp-{s}", "wb") as fh:
+                fh.write(plans[s]["head"])
+                fh.truncate(plans[s]["size"])
+    if dist is not None:
+        dist.barrier()
+
+    left_of = {s: sum(1 for n in names_of[s] if (s, n) in mine) for s in todo}
+    finished: List[str] = []
+
+    def tensor_written(s: str):
+        left_of[s] -= 1
+        if left_of[s] == 0:
+            finished.append(s)
+
+    writer = _InPlaceShardWriter(out_dir, plans, config.output_astype, on_gpu, tensor_written)
+
+    def publish_finished():
+        # a rank that has written its last tensor of a shard counts itself in; the one that completes the
+        # count renames the shard into place (a counter in the process group's store: no collective)
+        while finished:
+            s = finished.pop()
+            os.fsync(writer.fds[s])
+            n_done = store.add(f"shardmerge/{run_id}/{s}", 1) if store is not None else len(plans[s]["owners"])
+            if n_done == len(plans[s]["owners"]):
+                os.replace(out_dir / f".tmp-{s}", out_dir / s)
+                logger.info(f"rank {me}: shard {s} complete")
 
     # ---- this rank's finetune tensors are prefetched in processing order (loader.py); the base
     # comes from the broadcast, passthrough tensors from whichever model provides them
-    todo = [s for s in shards if not done[s]]
     my_order = [(s, name) for s in todo for name in names_of[s] if (s, name) in mine]
     schedule = []
     for (s, name) in my_order:
@@ -247,15 +468,7 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
         merger._loader = loader
     pos = {key: i for i, key in enumerate(my_order)}
 
-    # the shards this rank writes: a buffered, asynchronous ModelWriter over exactly those
     root_of = {s: si % world for si, s in enumerate(shards)}
-    my_shards = [s for s in todo if root_of[s] == me]
-    writer = None
-    if my_shards:
-        sub_index = {"metadata": index.model_indexes[base_uri].get("metadata", {}),
-                     "weight_map": {n: s for s in my_shards for n in names_of[s]}}
-        writer = ModelWriter(base_index=sub_index, output_path=out_dir, layer_order=layer_order,
-                             output_astype=config.output_astype, write_index=False)
 
     def block_layout(s):
         block = [n for n in names_of[s] if ShardLayer(0, s, n, False).layer_number >= 0] if fourier else []
@@ -265,77 +478,92 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             total += (metas[s][n][2] + 255) // 256 * 256
         return block, offs, total
 
+    window = max(1, int(os.environ.get("SHARDMERGE_BCAST_WINDOW", "3")))
     reader = _BaseShardReader(index, base_uri, pinned=on_gpu)
     mine_as_root = [s for s in todo if root_of[s] == me]
-    if mine_as_root:
-        _, offs0, total0 = block_layout(mine_as_root[0])
-        reader.start(mine_as_root[0], offs0, total0)
+    for s in mine_as_root[:2]:
+        _, offs0, total0 = block_layout(s)
+        reader.start(s, offs0, total0)
+    inflight: Dict[str, tuple] = {}                       # shard -> (device buffer, work handle, block, offsets)
+    issued = 0
+    via_host = dist is not None and on_gpu and dist.get_backend() != "nccl"      # (the gloo rehearsal above)
 
-    try:
-        for s in todo:
-            root = root_of[s]
+    def issue_broadcasts(upto: int):
+        """payloads of todo[issued : upto] on their way: every rank issues the same broadcasts in the same order"""
+        nonlocal issued
+        while issued < min(upto, len(todo)):
+            s = todo[issued]
+            issued += 1
             block, offs, total = block_layout(s)
-            flat = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-            if me == root and total:
-                host = reader.take(s, offs, total)
-                flat.copy_(host, non_blocking=True)
-                nxt = [q for q in mine_as_root if q > s]
-                if nxt:                                   # read the next base shard during this merge
-                    _, offs_n, total_n = block_layout(nxt[0])
-                    reader.start(nxt[0], offs_n, total_n)
-            if dist is not None and total:
-                dist.broadcast(flat, src=root)            # THE collective: RCCL over xGMI
-            views = {}
-            for n in block:
-                shape, dt, nbytes = metas[s][n]
-                views[n] = flat[offs[n][0]:offs[n][0] + nbytes].view(_ST_DTYPES[dt]).reshape(shape)
+            flat = torch.empty(max(total, 1), dtype=torch.uint8, device="cpu" if via_host else dev, pin_memory=via_host)
+            work = None
+            if total:
+                if me == root_of[s]:
+                    flat.copy_(reader.take(s, offs, total), non_blocking=True)
+                    nxt = [q for q in mine_as_root if q > s][:2]
+                    for q in nxt:                         # read the next base shards of this root meanwhile
+                        _, offs_n, total_n = block_layout(q)
+                        reader.start(q, offs_n, total_n)
+                if dist is not None and world > 1:
+                    work = dist.broadcast(flat, src=root_of[s], async_op=True)      # THE collective: RCCL over xGMI
+            inflight[s] = (flat, work, block, offs)
 
-            merged: Dict[str, torch.Tensor] = {}
-            for name in names_of[s]:
-                if (s, name) not in mine:
-                    continue
-                sl = ShardLayer(rank_of[name], s, name, False)
-                if loader is not None:
-                    loader.begin_layer(pos[(s, name)])
-                if sl.layer_number >= 0 and fourier:
-                    out = await _merge_block_tensor(merger, engine, sl, views[name])
-                else:
-                    out = await merger._merge_layer(sl, str(dev))
-                out = out.detach().to(config.output_astype)
-                if me == root:
-                    writer.add_tensor(name, out)          # asynchronous pinned copy, written with the shard
-                else:
-                    merged[name] = out
-            # results of the other ranks travel to the writer rank, one message per rank
-            if dist is not None and world > 1:
-                for r in range(world):
-                    theirs = [n for n in names_of[s] if owner_of[(s, n)] == r]
-                    if r == root or not theirs:
+    t_wait = t_merge = 0.0
+    t_start = time.time()
+    try:
+        for si, s in enumerate(todo):
+            issue_broadcasts(si + window)
+            flat, work, block, offs = inflight.pop(s)
+            if any((s, n) in mine for n in names_of[s]):
+                t0 = time.time()
+                if work is not None:
+                    work.wait()
+                t_wait += time.time() - t0
+                if via_host:
+                    flat = flat.to(dev, non_blocking=True)
+                views = {}
+                for n in block:
+                    shape, dt, nbytes = metas[s][n]
+                    views[n] = flat[offs[n][0]:offs[n][0] + nbytes].view(_ST_DTYPES[dt]).reshape(shape)
+                t0 = time.time()
+                for name in names_of[s]:
+                    if (s, name) not in mine:
                         continue
-                    sizes = [metas[s][n][0] for n in theirs]
-                    numels = [int(torch.Size(sh).numel()) for sh in sizes]
-                    if me == r:
-                        buf = torch.cat([merged[n].reshape(-1) for n in theirs]) if len(theirs) > 1 else merged[theirs[0]].reshape(-1).contiguous()
-                        dist.send(buf, dst=root)
-                    elif me == root:
-                        buf = torch.empty(sum(numels), dtype=config.output_astype, device=dev)
-                        dist.recv(buf, src=r)
-                        o = 0
-                        for n, sh, ne in zip(theirs, sizes, numels):
-                            writer.add_tensor(n, buf[o:o + ne].view(sh))
-                            o += ne
-            del flat, views, merged
+                    sl = ShardLayer(rank_of[name], s, name, False)
+                    if loader is not None:
+                        loader.begin_layer(pos[(s, name)])
+                    if sl.layer_number >= 0 and fourier:
+                        out = await _merge_block_tensor(merger, engine, sl, views[name])
+                    else:
+                        out = await merger._merge_layer(sl, str(dev))
+                    writer.add(s, name, out)              # asynchronous pinned copy, written at its offset
+                    del out
+                    publish_finished()
+                if on_gpu:
+                    torch.cuda.current_stream(dev).synchronize()
+                t_merge += time.time() - t0
+                del views
+            elif work is not None:
+                work.wait()                               # (the buffer must outlive the collective)
+            del flat
     finally:
         reader.close()
         if loader is not None:
             loader.close()
             merger._loader = None
+    writer.jobs.join()
+    publish_finished()
+    writer.close()
+    busy = time.time() - t_start
+    logger.info(f"rank {me}: merged {len(mine)} tensors in {busy:.2f} s; waited {t_wait:.2f} s for base shards "
+                f"(idle {100.0 * t_wait / max(busy, 1e-9):.1f} %)")
 
-    if writer is not None:
-        writer.finalize()                                 # raises if one of this rank's shards is incomplete
     if dist is not None:
         dist.barrier()
     if me == 0:
+        missing = [s for s in todo if not (out_dir / s).exists()]
+        if missing:
+            raise RuntimeError(f"Incomplete model output: shards {missing} were not completed")
         with open(out_dir / "model.safetensors.index.json", "w") as fh:
             json.dump(index.model_indexes[base_uri], fh, indent=2)
         with open(out_dir / "README.md", "w") as fh:

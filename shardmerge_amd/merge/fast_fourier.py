@@ -82,6 +82,13 @@ class FourierMerge(MergeTensorsBase):
                 shape = tuple(int(v) for v in rec["shape"])
                 if not shape:
                     continue
+                # a layer only ONE finetune covers (K = 1) is never transformed: any shape goes
+                try:
+                    number = ShardLayer(0, shard, name, False).layer_number
+                except ValueError:
+                    continue                  # (the merge itself reports unknown names, as the reference does)
+                if sum(1 for m in self.config.finetune_merge if m.use_layer_index(number)) < 2:
+                    continue
                 if shape not in seen:
                     if len(shape) <= 2:
                         rows, cols = (1, shape[0]) if len(shape) == 1 else shape

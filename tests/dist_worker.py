@@ -1,5 +1,5 @@
-"""Worker of tests/test_distributed_gloo.py: one rank of a gloo (CPU) job that runs the
-partitioned merge with the CPU work-group emulator as its device."""
+"""Worker of tests/test_distributed_gloo.py: one rank of a gloo job that runs the partitioned merge with the CPU
+work-group emulator as its device (or, SHARDMERGE_TEST_REAL_ENGINE=1, the HIP library on the one GPU of the box)."""
 import asyncio
 import sys
 from pathlib import Path
@@ -19,10 +19,13 @@ def main():
     import logging
     logging.basicConfig(level=logging.INFO)
     torch.set_num_threads(1)
+    import os
     cfg = MergeConfig.from_yaml(sys.argv[1])
-    distributed.ENGINE_FACTORY = emul_engine
+    real = os.environ.get("SHARDMERGE_TEST_REAL_ENGINE") == "1"      # the GPU tier: real engines, several ranks on one card (gloo)
+    if not real:
+        distributed.ENGINE_FACTORY = emul_engine
     idx = LocalModelIndex(cfg.storage_path)
-    asyncio.run(distributed.run_partitioned_merge(cfg, idx, "cpu"))
+    asyncio.run(distributed.run_partitioned_merge(cfg, idx, "cuda" if real else "cpu"))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()

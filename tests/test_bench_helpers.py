@@ -65,12 +65,25 @@ def test_default_workload_is_the_metrics_configuration(bench, monkeypatch):
 def test_traffic_file_is_refused_for_another_workload(bench, tmp_path, monkeypatch):
     import json
     (tmp_path / "profiles").mkdir()
-    json.dump({"_meta": {"workload": "llama3-8b", "k": 2}, "f2_cols_fwd": {"hbm_bytes_per_launch": 5.0}},
+    sha = bench.csrc_stamp()
+    json.dump({"_meta": {"workload": "llama3-8b", "k": 2, "csrc_sha": sha}, "f2_cols_fwd": {"hbm_bytes_per_launch": 5.0}},
               open(tmp_path / "profiles" / "traffic_latest.json", "w"))
+    real_repo = bench.REPO
+    monkeypatch.setattr(bench, "csrc_stamp", lambda: sha)
     monkeypatch.setattr(bench, "REPO", tmp_path)
     assert bench.load_traffic("llama3-8b", 2, "f2_cols_fwd") == 5.0
     assert bench.load_traffic("llama3-70b-slice", 3, "f2_cols_fwd") is None
     assert bench.load_traffic("llama3-8b", 3, "f2_cols_fwd") is None
+    # ... and for other kernel sources than the ones it was measured on
+    monkeypatch.setattr(bench, "csrc_stamp", lambda: "0" * 16)
+    assert bench.load_traffic("llama3-8b", 2, "f2_cols_fwd") is None
+    assert len(sha) == 16 and real_repo.exists()
+
+
+def test_moved_bytes_model(bench):
+    assert bench.moved_bytes_per_elem(2, "exact") == 56 and bench.moved_bytes_per_elem(3, "exact") == 89
+    assert bench.moved_bytes_per_elem(3, "reference_cpu") > bench.moved_bytes_per_elem(3, "exact")
+    assert bench.moved_bytes_per_elem(3, "reference_cpu") < bench.alg_bytes_per_elem(3)
 
 
 def test_gpus_n_outside_torchrun_starts_the_ranks_as_a_child(bench, monkeypatch):

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks run the partitioned merge (tensor partition by
-LPT, ONE broadcast per base shard, per-rank part files, shard assembly) and must
-produce byte-identical shards to the single-process writer path."""
+"""N > 1 path on CPU: gloo ranks run the partitioned merge (tensors handed out in shard order to the
+least-loaded rank, ONE asynchronous broadcast per base shard issued a few shards ahead, every rank writing
+its results into the pre-sized output shards in place) and must produce the tensors the single-process
+writer path produces, shard for shard."""
 import os
 import socket
 import subprocess
@@ -22,6 +23,44 @@ def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def test_partition_in_shard_order_is_balanced_on_every_prefix():
+    import random
+    rnd = random.Random(7)
+    costs, groups = [], []
+    for shard in range(40):                                  # a 70B-like block per shard: sizes two orders of magnitude apart
+        for c in (5.8, 5.8, 6.05, 1.83, 1.83, 0.56, 0.56, 0.2, 0.2):
+            costs.append(c * rnd.uniform(0.9, 1.1))
+            groups.append(shard)
+    world = 8
+    owner = distributed.partition_in_order(costs, groups, world)
+    assert owner == distributed.partition_in_order(costs, groups, world)
+    for upto in (3, 10, 25, 40):                             # after any number of shards no rank is more than one large tensor behind
+        loads = [sum(c for c, g, o in zip(costs, groups, owner) if o == r and g < upto) for r in range(world)]
+        assert max(loads) - min(loads) <= max(costs) + 1e-9, (upto, loads)
+    assert distributed.est_ms((28672, 8192), 3) > 2.5 * distributed.est_ms((8192, 8192), 3) > 2.5 * distributed.est_ms((1024, 8192), 3)
+    assert distributed.est_ms((8192,), 3) < 0.5
+
+
+def test_output_shard_header_is_safetensors_own_bytes():
+    """the in-place writer lays a shard out itself: header and payload order must be exactly what
+    safetensors.torch.save produces for the same tensors"""
+    from safetensors.torch import save
+    t = {"model.layers.1.b": torch.randn(3, 4).bfloat16(), "model.layers.0.a": torch.randn(5).bfloat16(),
+         "lm_head.weight": torch.randn(2, 2, 2).bfloat16(), "z": torch.randn(2).float()}
+    blob = save(t, metadata={"format": "pt"})           # (one key: safetensors keeps metadata in a hash map, several keys come in any order)
+    names = {torch.bfloat16: "BF16", torch.float32: "F32"}
+    entries = [(k, names[v.dtype], list(v.shape)) for k, v in t.items()]
+    head, offs = distributed.shard_header(entries, {"format": "pt"})
+    assert blob[:len(head)] == head
+    payload = b"".join(t[k].contiguous().view(torch.uint8).numpy().tobytes() for k in sorted(offs, key=lambda k: offs[k][0]))
+    assert blob[len(head):] == payload
+    # with the run's stamp in the metadata the file still reads back
+    from safetensors.torch import load
+    head2, offs2 = distributed.shard_header(entries, {"format": "pt", "shardmerge_config": "abc"})
+    back = load(head2 + payload)
+    assert offs2 == offs and all(torch.equal(back[k], t[k]) for k in t)
 
 
 def test_partition_lpt_is_balanced_and_deterministic():
@@ -68,7 +107,7 @@ def test_two_rank_merge_equals_single_process(tmp_path, monkeypatch):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
 
     a, b = one / "merged", two / "merged"
-    assert not list(b.glob(".part-*")) and not list(b.glob(".tmp-*"))      # results travel rank to rank, shards are written once
+    assert not list(b.glob(".part-*")) and not list(b.glob(".tmp-*"))      # every shard was completed and renamed into place
     assert sorted(p.name for p in a.iterdir()) == sorted(p.name for p in b.iterdir())
     assert (a / "README.md").read_text() == (b / "README.md").read_text()
     for shard in gi.CLI_SHARDS:
@@ -108,3 +147,182 @@ def test_two_rank_merge_resumes_at_shard_granularity(tmp_path):
     assert "already complete" in log
     assert (out / keep).stat().st_mtime_ns == stamp
     assert {s: (out / s).read_bytes() for s in shards} == before
+
+
+_BLOCK = [("self_attn.q_proj.weight", (128, 128)), ("self_attn.k_proj.weight", (32, 128)), ("input_layernorm.weight", (128,)),
+          ("mlp.up_proj.weight", (448, 256)), ("mlp.down_proj.weight", (256, 448))]
+
+
+def _blk(i, *which):
+    return [(f"model.layers.{i}.{c}", sh) for c, sh in _BLOCK if c in which]
+
+
+UNEVEN_SHARDS = {
+    # deliberately uneven: big tensors alone, many small ones together, the embedding with the finetune's
+    # EXTENDED vocabulary (passthrough from the is_input model: its shape, not the base's)
+    "model-00001-of-00005.safetensors": [("model.embed_tokens.weight", (64, 64))] + _blk(0, "mlp.up_proj.weight"),
+    "model-00002-of-00005.safetensors": _blk(0, "self_attn.q_proj.weight", "self_attn.k_proj.weight", "input_layernorm.weight")
+                                        + _blk(1, "self_attn.k_proj.weight", "input_layernorm.weight") + _blk(2, "self_attn.k_proj.weight", "input_layernorm.weight"),
+    "model-00003-of-00005.safetensors": _blk(0, "mlp.down_proj.weight") + _blk(1, "mlp.up_proj.weight", "mlp.down_proj.weight"),
+    "model-00004-of-00005.safetensors": _blk(1, "self_attn.q_proj.weight") + _blk(2, "self_attn.q_proj.weight", "mlp.up_proj.weight"),
+    "model-00005-of-00005.safetensors": _blk(2, "mlp.down_proj.weight") + [("model.norm.weight", (64,)), ("lm_head.weight", (64, 64))],
+}
+N_UNEVEN = sum(len(v) for v in UNEVEN_SHARDS.values())
+
+
+def write_uneven_model(root: Path, n_ft: int = 3) -> Path:
+    import json
+    import yaml
+    from safetensors.torch import save_file
+    storage = root / "storage"
+    uris = ["org/base"] + [f"org/ft{i}" for i in range(1, n_ft + 1)]
+    for which, uri in enumerate(uris):
+        d = storage / uri
+        d.mkdir(parents=True, exist_ok=True)
+        weight_map = {}
+        ti = 0
+        for shard, items in UNEVEN_SHARDS.items():
+            tens = {}
+            for name, shape in items:
+                ti += 1
+                g = torch.Generator().manual_seed(300 + ti)
+                base = (torch.randn(*shape, generator=g) * 0.02).to(torch.bfloat16)
+                if which:
+                    g2 = torch.Generator().manual_seed(300 + 100 * which + ti)
+                    base = (base.float() + torch.randn(*shape, generator=g2) * (0.002 + 0.0005 * which)).to(torch.bfloat16)
+                    if which == 1 and name == "model.embed_tokens.weight":        # ft1 (is_input) extends the vocabulary
+                        base = torch.cat([base, torch.full((8, shape[1]), 0.01, dtype=torch.bfloat16)])
+                tens[name] = base
+                weight_map[name] = shard
+            save_file(tens, str(d / shard), metadata={"format": "pt"})
+        with open(d / "model.safetensors.index.json", "w") as f:
+            json.dump({"metadata": {"total_size": 0}, "weight_map": weight_map}, f)
+    cfg = {"output_base_model": "org/base",
+           "finetune_merge": [{"model": f"org/ft{i}", "base": "org/base", "alpha": 0.2 + 0.1 * i, "is_input": i == 1} for i in range(1, n_ft + 1)],
+           "output_dir": str(root / "merged"), "output_dtype": "bfloat16", "device": "cpu",
+           "cache_dir": str(root / "cache"), "storage_dir": str(storage)}
+    p = root / "merge.yaml"
+    with open(p, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return p
+
+
+def _run_ranks(cfg, world, extra_env=None):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(cfg)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return outs
+
+
+def test_four_ranks_on_uneven_shards_equal_single_process(tmp_path, monkeypatch):
+    """4 gloo ranks, K = 3, five shards of very different weight (a rank owns several tensors of one shard and none
+    of another), the embedding taken from a finetune with an extended vocabulary: the tensors must equal the
+    single-process run's, no rank may spend its time waiting for base shards, and a second run after deleting
+    one shard redoes exactly that shard."""
+    import re
+    from tests.emul.loader import emul_engine, build
+    build()
+    one = tmp_path / "one"
+    one.mkdir()
+    cfg1 = write_uneven_model(one)
+    from shardmerge_amd import engine as engine_mod
+    eng = emul_engine()
+    monkeypatch.setattr(engine_mod, "get_engine", lambda device=None: eng)
+    from shardmerge_amd.__main__ import cli
+    res = CliRunner().invoke(cli, ["merge", str(cfg1)])
+    assert res.exit_code == 0, res.output
+
+    four = tmp_path / "four"
+    four.mkdir()
+    cfg4 = write_uneven_model(four)
+    outs = _run_ranks(cfg4, 4)
+    a, b = one / "merged", four / "merged"
+    assert not list(b.glob(".tmp-*"))
+    assert sorted(p.name for p in a.iterdir()) == sorted(p.name for p in b.iterdir())
+    for shard in UNEVEN_SHARDS:
+        with safe_open(str(a / shard), framework="pt") as fa, safe_open(str(b / shard), framework="pt") as fb:
+            assert list(fa.keys()) == list(fb.keys())
+            for k in fa.keys():
+                assert torch.equal(fa.get_tensor(k), fb.get_tensor(k)), k
+    with safe_open(str(b / "model-00001-of-00005.safetensors"), framework="pt") as fb:
+        assert tuple(fb.get_tensor("model.embed_tokens.weight").shape) == (72, 64)        # the provider's shape
+    idle = [float(m) for o in outs for m in re.findall(r"idle ([0-9.]+) %", o)]
+    assert len(idle) == 4 and max(idle) < 35.0, idle          # (emulator on CPU: merges take milliseconds; on the GPU box see INTEGRATION.md)
+    counts = [int(m) for o in outs for m in re.findall(r"rank \d+/4: (\d+) of %d tensors" % N_UNEVEN, o)]
+    assert sorted(counts)[0] >= 2 and sum(counts) == N_UNEVEN
+
+    # resume: a complete shard is kept (same bytes, same mtime), a missing one is redone - decided once, on rank 0
+    shards = sorted(UNEVEN_SHARDS)
+    before = {s: (b / s).read_bytes() for s in shards}
+    stamp = (b / shards[0]).stat().st_mtime_ns
+    (b / shards[2]).unlink()
+    outs = _run_ranks(cfg4, 4)
+    assert any("4 shard(s) already complete" in o for o in outs)
+    assert (b / shards[0]).stat().st_mtime_ns == stamp
+    assert {s: (b / s).read_bytes() for s in shards} == before
+    # a run with other options does not trust those shards
+    cfgdoc = (four / "merge.yaml").read_text()
+    (four / "merge.yaml").write_text(cfgdoc + "merge_options:\n  cutoff_pct: 0.05\n")
+    outs = _run_ranks(four / "merge.yaml", 4)
+    assert not any("already complete" in o for o in outs)
+    assert (b / shards[2]).read_bytes() != before[shards[2]]
+
+
+@pytest.mark.gpu
+def test_four_ranks_with_real_engines_share_the_gpu(tmp_path):
+    """The partitioned merge with the HIP library in every rank: 4 processes on the box's one GPU (gloo carries the
+    base shards through host memory - RCCL refuses two ranks on one device; the 8-GPU run over RCCL is the
+    driver's), uneven shards, several tensors of one shard on a non-root rank, then a resume run.  The tensors must
+    equal the single-GPU CLI run's bit for bit (same kernels, same inputs)."""
+    import re
+    one = tmp_path / "one"
+    one.mkdir()
+    cfg1 = write_uneven_model(one)
+    doc = cfg1.read_text().replace("device: cpu", "device: cuda")
+    cfg1.write_text(doc)
+    from shardmerge_amd.__main__ import cli
+    res = CliRunner().invoke(cli, ["merge", str(cfg1)])
+    assert res.exit_code == 0, res.output
+    four = tmp_path / "four"
+    four.mkdir()
+    cfg4 = write_uneven_model(four)
+    cfg4.write_text(cfg4.read_text().replace("device: cpu", "device: cuda"))
+    env = {"SHARDMERGE_TEST_REAL_ENGINE": "1", "SHARDMERGE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    port = free_port()
+    procs = []
+    for r in range(4):
+        e = dict(os.environ, RANK=str(r), WORLD_SIZE="4", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(cfg4)], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    a, b = one / "merged", four / "merged"
+    assert not list(b.glob(".tmp-*"))
+    for shard in UNEVEN_SHARDS:
+        with safe_open(str(a / shard), framework="pt") as fa, safe_open(str(b / shard), framework="pt") as fb:
+            assert list(fa.keys()) == list(fb.keys())
+            for k in fa.keys():
+                assert torch.equal(fa.get_tensor(k), fb.get_tensor(k)), k
+    owners = {}
+    for o in outs:
+        for m in re.finditer(r"rank (\d+)/4: (\d+) of", o):
+            owners[int(m.group(1))] = int(m.group(2))
+    assert len(owners) == 4 and min(owners.values()) >= 2
+    shards = sorted(UNEVEN_SHARDS)
+    before = {s: (b / s).read_bytes() for s in shards}
+    (b / shards[1]).unlink()
+    procs = []
+    port = free_port()
+    for r in range(4):
+        e = dict(os.environ, RANK=str(r), WORLD_SIZE="4", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "tests" / "dist_worker.py"), str(cfg4)], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert {s: (b / s).read_bytes() for s in shards} == before

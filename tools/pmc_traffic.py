@@ -40,7 +40,9 @@ NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI
          "KI1x1Q": "i1_cols_inv", "KI1x2Q": "i1_cols_inv", "KSpecNorm": "spec_norm", "KSpecRescale": "spec_rescale",
          "KDeltaNorms": "delta_norms", "KAddition": "addition_merge", "KSerialNorm": "serial_norm",
          "KDftp": "dft_across_slices", "KDftpPairs": "dft_across_slices", "KTranspose": "transpose", "KPair1d": "pair_1d",
-         "KSelect2": "select_lvl2", "KSelect2Cull": "select_lvl2_cull", "KBlendSel": "blend", "KSpecCheck": "select_spec_check", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine"}
+         "KSelect2": "select_lvl2", "KSelect2Cull": "select_lvl2_cull", "KBlendSel": "blend", "KSpecCheck": "select_spec_check", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine",
+         "KAtenPre": "aten_norm_pre", "KAtenPreC": "aten_norm_pre", "KAtenPart": "aten_norm_part", "KAtenPartC": "aten_norm_part",
+         "KAtenWalk": "aten_norm_walk", "KAtenWalkC": "aten_norm_walk", "KClassEmf": "class_norm_stats"}
 
 
 def main():
@@ -60,7 +62,9 @@ def main():
         rec["hbm_bytes_per_launch"] = (rec["fetch_bytes"] + rec["write_bytes"]) / rec["launches"]
     printable = dict(out)
     if len(sys.argv) > 5:
-        out["_meta"] = {"workload": sys.argv[4], "k": int(sys.argv[5]),
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        import bench
+        out["_meta"] = {"workload": sys.argv[4], "k": int(sys.argv[5]), "csrc_sha": bench.csrc_stamp(),
                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes (tools/traffic_run.sh)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(printable.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
