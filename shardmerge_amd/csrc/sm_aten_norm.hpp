@@ -286,7 +286,16 @@ SM_HD void k_aten_scan(Ex& ex, const AtenScanParams& p) {
     ex.each(st, [&](int tid, EmptyState&) {
         const int lane = tid & 7, b = tid >> 3;
         double sum = 0.0;
-        for (size_t c = (size_t)b * per; c < (size_t)(b + 1) * per && c < p.nchunks; ++c) sum += base[c * 8 + lane];
+        const size_t c0 = (size_t)b * per, c1 = (c0 + per < p.nchunks) ? c0 + per : p.nchunks;
+        size_t c = c0;
+        for (; c + 8 <= c1; c += 8) {                              // 8 independent loads in flight, then the adds
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(c + u) * 8 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; c < c1; ++c) sum += base[c * 8 + lane];
         blk[b * 8 + lane] = sum;
     });
     ex.sync();
@@ -294,10 +303,16 @@ SM_HD void k_aten_scan(Ex& ex, const AtenScanParams& p) {
         const int lane = tid & 7, b = tid >> 3;
         double run = 0.0;
         for (int q = 0; q < b; ++q) run += blk[q * 8 + lane];
-        for (size_t c = (size_t)b * per; c < (size_t)(b + 1) * per && c < p.nchunks; ++c) {
-            run += base[c * 8 + lane];
-            base[c * 8 + lane] = run;
+        const size_t c0 = (size_t)b * per, c1 = (c0 + per < p.nchunks) ? c0 + per : p.nchunks;
+        size_t c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(c + u) * 8 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { run += v[u]; base[(c + u) * 8 + lane] = run; }
         }
+        for (; c < c1; ++c) { run += base[c * 8 + lane]; base[c * 8 + lane] = run; }
     });
 }
 
@@ -356,9 +371,29 @@ constexpr int ATEN_STAGE_ROWS = 8;
 constexpr int ATEN_STAGES = ATEN_ROWS_PER_THREAD / ATEN_STAGE_ROWS;
 constexpr int ATEN_STAGE_PITCH = ATEN_STAGE_ROWS * 8 + 4;          // floats per thread: 256 B + 16 B (bank spread)
 constexpr size_t ATEN_PART_LDS_FLOATS = (size_t)ATEN_THREADS * ATEN_STAGE_PITCH + ATEN_THREADS * ATEN_STAGE_ROWS / 4 + 64;
-struct AtenPartState { AtenAcc a[16]; AtenSum s[16]; float pf[ATEN_STAGE_ROWS][8]; uint32_t pw[ATEN_STAGE_ROWS]; double red[8]; };
-template <int KIND, class Ex>
+// the prefetched rows stay RAW (two 16-byte vectors per row: a 16-bit delta's finetune and base pieces, or the two
+// halves of an fp32 row) and are decoded when they go to LDS: a load whose result is branched on (dtype, "has a
+// base", "row exists") is waited for on the spot - the addresses are clamped instead and all loads of a stage issue
+// back to back
+// MODE: 0 = 16-bit delta with a base (raw prefetch), 1 = fp32 without a base (raw prefetch), 2 = any other
+// signal (generic loader), 3 = the slerp class of two planes (AtenSrc kind 1, generic loader)
+enum { ATEN_PART_RAW16 = 0, ATEN_PART_RAW32 = 1, ATEN_PART_SIGNAL = 2, ATEN_PART_CLASS = 3 };
+SM_HD int aten_part_mode(const AtenSrc& a) {
+    if (a.kind != 0) return ATEN_PART_CLASS;
+    if (a.sig.prescale != 1.f || !a.sig.x) return ATEN_PART_SIGNAL;
+    if (a.sig.dtype != DT_F32 && a.sig.base) return ATEN_PART_RAW16;
+    if (a.sig.dtype == DT_F32 && !a.sig.base) return ATEN_PART_RAW32;
+    return ATEN_PART_SIGNAL;
+}
+template <bool RAW> struct AtenPartBuf;
+template <> struct AtenPartBuf<true> { u32x4 raw[ATEN_STAGE_ROWS][2]; };
+template <> struct AtenPartBuf<false> { float pf[ATEN_STAGE_ROWS][8]; uint32_t pw[ATEN_STAGE_ROWS]; };
+template <int MODE> struct AtenPartStateT { AtenAcc a[16]; AtenSum s[16]; AtenPartBuf<(MODE < 2)> b; double red[8]; };
+template <int MODE, class Ex>
 SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
+    constexpr int KIND = MODE == ATEN_PART_CLASS ? 1 : 0;
+    constexpr bool raw16 = MODE == ATEN_PART_RAW16, raw32 = MODE == ATEN_PART_RAW32;
+    using AtenPartState = AtenPartStateT<MODE>;
     typename Ex::template State<AtenPartState> st;
     ex.init(st);
     const int sig = ex.bid() % p.nsig;
@@ -369,8 +404,8 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     const float thr = (KIND == 1 && s.thr) ? *s.thr : 0.f;
     float* stage = ex.lds() + LDS_SCRATCH_FLOATS;                   // [256 threads][8 rows][8] (+ pad)
     uint8_t* w2row = (uint8_t*)(stage + (size_t)ATEN_THREADS * ATEN_STAGE_PITCH);      // [2048]: a row's "counts twice" bits
-    AtenSum* ent = (AtenSum*)stage;                                 // after the stages: [8 lanes][256 threads]
-    AtenSum* seg = ent + 8 * ATEN_THREADS;                          // [8 lanes][32 groups]
+    AtenSum* ent = (AtenSum*)stage;                                 // after the stages: [256 threads][8 lanes + 1 pad]
+    AtenSum* seg = ent + 9 * ATEN_THREADS;                          // [32 groups][8 lanes]
     const size_t slot = ((size_t)sig * p.nchunks + chunk) * 8;
     // a lane whose sum cannot be a binade below the prediction anywhere in the chunk (the prefix at the chunk's
     // START, less a margin for the sum's bias and the sampling error, is already in it) gets one summary only
@@ -384,15 +419,37 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     const size_t row0 = chunk * ATEN_CHUNK_ROWS;
     // stage `sidx`: this thread fetches rows q = i * 256 + tid of it (owner q / 8, the owner's row q % 8): 8
     // consecutive threads read 8 consecutive rows
+    auto stage_row = [&](int tid, int sidx, int i) -> size_t {
+        const int qq = i * ATEN_THREADS + tid;
+        return row0 + (size_t)(qq / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (qq % 8);
+    };
     auto fetch = [&](int tid, AtenPartState& q, int sidx) {
+        if constexpr (raw16) {
+            const u32x4* X = (const u32x4*)s.sig.x;
+            const u32x4* B = (const u32x4*)s.sig.base;
 #pragma unroll
-        for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
-            const int qq = i * ATEN_THREADS + tid;
-            const size_t r = row0 + (size_t)(qq / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (qq % 8);
-            uint32_t w2 = 0u;
-            if (r < rows) w2 = aten_load_row<KIND>(s, wr, thr, r, q.pf[i]);
-            else { for (int e = 0; e < 8; ++e) q.pf[i][e] = 0.f; }
-            q.pw[i] = w2;
+            for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
+                const size_t r = stage_row(tid, sidx, i);
+                const size_t rc = r < rows ? r : rows - 1;
+                q.b.raw[i][0] = X[rc]; q.b.raw[i][1] = B[rc];
+            }
+        } else if constexpr (raw32) {
+            const u32x4* X = (const u32x4*)s.sig.x;
+#pragma unroll
+            for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
+                const size_t r = stage_row(tid, sidx, i);
+                const size_t rc = r < rows ? r : rows - 1;
+                q.b.raw[i][0] = X[2 * rc]; q.b.raw[i][1] = X[2 * rc + 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
+                const size_t r = stage_row(tid, sidx, i);
+                uint32_t w2 = 0u;
+                if (r < rows) w2 = aten_load_row<KIND>(s, wr, thr, r, q.b.pf[i]);
+                else { for (int e = 0; e < 8; ++e) q.b.pf[i][e] = 0.f; }
+                q.b.pw[i] = w2;
+            }
         }
     };
     ex.each(st, [&](int tid, AtenPartState& q) {
@@ -406,10 +463,30 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
 #pragma unroll
             for (int i = 0; i < ATEN_STAGE_ROWS; ++i) {
                 const int qq = i * ATEN_THREADS + tid;
+                float v[8];
+                uint32_t w2bits = 0u;
+                if constexpr (raw16) {
+                    float f[8], bb[8];
+                    decode16x8(q.b.raw[i][0], s.sig.dtype, f);
+                    decode16x8(q.b.raw[i][1], s.sig.dtype, bb);
+                    const bool live = stage_row(tid, sidx, i) < rows;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = live ? f[e] - bb[e] : 0.f;
+                } else if constexpr (raw32) {
+                    const bool live = stage_row(tid, sidx, i) < rows;
+                    const u32x4 lo4 = q.b.raw[i][0], hi4 = q.b.raw[i][1];
+                    const uint32_t w[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = live ? u2f(w[e]) : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = q.b.pf[i][e];
+                    w2bits = q.b.pw[i];
+                }
                 float* d = stage + (size_t)(qq / 8) * ATEN_STAGE_PITCH + (qq % 8) * 8;
-                cf4 lo = {q.pf[i][0], q.pf[i][1], q.pf[i][2], q.pf[i][3]}, hi = {q.pf[i][4], q.pf[i][5], q.pf[i][6], q.pf[i][7]};
+                cf4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
                 ((cf4*)d)[0] = lo; ((cf4*)d)[1] = hi;
-                if (KIND == 1) w2row[qq] = (uint8_t)q.pw[i];
+                if (KIND == 1) w2row[qq] = (uint8_t)w2bits;
             }
         });
         ex.sync();
@@ -440,23 +517,25 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
         for (int i = 0; i < 16; ++i) q.s[i] = ((i & 1) && !((two >> (i / 2)) & 1u)) ? aten_sum_stop() : aten_sum_of(q.a[i]);
     });
     for (int cand = 0; cand < 2; ++cand) {
+        // (a thread's 8 summaries are 9 slots apart from the next thread's and the readers take the 8 lanes of one
+        // source thread side by side: 2-way bank conflicts at most - lane-major they were 32-way)
         ex.each(st, [&](int tid, AtenPartState& q) {
 #pragma unroll
-            for (int l = 0; l < 8; ++l) ent[l * ATEN_THREADS + tid] = cand ? q.s[2 * l + 1] : q.s[2 * l];
+            for (int l = 0; l < 8; ++l) ent[tid * 9 + l] = cand ? q.s[2 * l + 1] : q.s[2 * l];
         });
         ex.sync();
-        ex.each(st, [&](int tid, AtenPartState&) {                  // 8 lanes x 32 groups of 8 threads
-            const int lane = tid >> 5, g = tid & 31;
+        ex.each(st, [&](int tid, AtenPartState&) {                  // 32 groups of 8 threads x 8 lanes
+            const int lane = tid & 7, g = tid >> 3;
             AtenSum run = aten_sum_identity();
-            for (int j = 0; j < 8; ++j) run = aten_compose(run, ent[lane * ATEN_THREADS + g * 8 + j]);
-            seg[lane * 32 + g] = run;
+            for (int j = 0; j < 8; ++j) run = aten_compose(run, ent[(g * 8 + j) * 9 + lane]);
+            seg[g * 8 + lane] = run;
             p.grp[((slot + lane) * 2 + cand) * ATEN_GROUPS + g] = run;
         });
         ex.sync();
         ex.each(st, [&](int tid, AtenPartState&) {
             if (tid < 8) {
                 AtenSum run = aten_sum_identity();
-                for (int g = 0; g < 32; ++g) run = aten_compose(run, seg[tid * 32 + g]);
+                for (int g = 0; g < 32; ++g) run = aten_compose(run, seg[g * 8 + tid]);
                 p.rec[(slot + tid) * 2 + cand] = run;
                 if (cand == 0) p.epred[slot + tid] = ep[tid];
             }

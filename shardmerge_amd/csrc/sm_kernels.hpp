@@ -2262,7 +2262,7 @@ struct SlerpConstParams {
 constexpr int EMF_LEVELS = 16;
 constexpr int EMF_VALS = EMF_LEVELS + 2;        // weighted count, sum of squares, EMF_LEVELS sums of rounded squares
 constexpr int EMF_MAX_SAMPLE = 16;              // at most one piece of 8 rows (64 plane elements) in every 16 is read ...
-constexpr size_t EMF_MIN_SAMPLED = (size_t)4 << 20;   // ... as long as this many elements are
+constexpr size_t EMF_MIN_SAMPLED = (size_t)2 << 20;   // ... as long as this many elements are
 struct ClassEmfParams {
     const float* reA; const float* reB;         // planes [Cb][R]
     const float* thr;                           // device scalar (cutoff threshold) or null (-> 0)
@@ -2297,20 +2297,17 @@ SM_HD void k_class_emf(Ex& ex, const ClassEmfParams& p) {
         for (int it = 0; it < p.iters; ++it) {
             const size_t piece = ((size_t)ex.bid() * p.iters + it) * (nt / 8) + (size_t)(tid / 8);
             const size_t r = piece * (8 * (size_t)p.sample) + (size_t)(tid % 8);
-            if (piece >= npieces || r >= rows) continue;
-            const size_t i0 = r * 8;
-            float a[8], b[8];
-            if (i0 + 8 <= p.n) {
-                const cf4 a0 = ((const cf4*)p.reA)[i0 / 4], a1 = ((const cf4*)p.reA)[i0 / 4 + 1];
-                const cf4 b0 = ((const cf4*)p.reB)[i0 / 4], b1 = ((const cf4*)p.reB)[i0 / 4 + 1];
-                a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-            } else {
-                for (int e = 0; e < 8; ++e) { a[e] = i0 + e < p.n ? p.reA[i0 + e] : 0.f; b[e] = i0 + e < p.n ? p.reB[i0 + e] : 0.f; }
-            }
+            // (the address is clamped instead of branched around: a load behind a branch is waited for on the spot;
+            // a ragged last row of fewer than 8 elements is left out of the sample)
+            const bool live = piece < npieces && r < rows && r * 8 + 8 <= p.n;
+            const size_t i0 = live ? r * 8 : 0;
+            const cf4 a0 = ((const cf4*)p.reA)[i0 / 4], a1 = ((const cf4*)p.reA)[i0 / 4 + 1];
+            const cf4 b0 = ((const cf4*)p.reB)[i0 / 4], b1 = ((const cf4*)p.reB)[i0 / 4 + 1];
+            const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool in = i0 + e < p.n && same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr);
+                const bool in = live && same_sign(a[e], b[e]) && !(fabsf(b[e]) < thr);
                 if (!in) continue;
                 const double w = (double)weight_at(wr, i0 + e);
                 const double ya = (double)a[e] * (double)a[e], yb = (double)b[e] * (double)b[e];

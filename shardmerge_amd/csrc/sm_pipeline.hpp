@@ -176,15 +176,17 @@ SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
 SM_KERNEL_TAG_LB(KAtenPre, AtenPreParams, "aten_norm_pre", k_aten_pre<0>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenPreC, AtenPreParams, "aten_norm_pre", k_aten_pre<1>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenScan, AtenScanParams, "aten_norm_scan", k_aten_scan(ex, p), 256, 4)
-SM_KERNEL_TAG_LB(KAtenPart, AtenPartParams, "aten_norm_part", k_aten_part<0>(ex, p), 256, 2)      // 16 running summaries per thread
-SM_KERNEL_TAG_LB(KAtenPartC, AtenPartParams, "aten_norm_part", k_aten_part<1>(ex, p), 256, 2)
+SM_KERNEL_TAG_LB(KAtenPart16, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW16>(ex, p), 256, 2)   // 16 running summaries per thread
+SM_KERNEL_TAG_LB(KAtenPart32, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW32>(ex, p), 256, 2)
+SM_KERNEL_TAG_LB(KAtenPart, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_SIGNAL>(ex, p), 256, 2)
+SM_KERNEL_TAG_LB(KAtenPartC, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_CLASS>(ex, p), 256, 2)
 SM_KERNEL_TAG_LB(KAtenWalk, AtenWalkParams, "aten_norm_walk", k_aten_walk<0>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenWalkC, AtenWalkParams, "aten_norm_walk", k_aten_walk<1>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finish(ex, p), 256, 4)
 // Every kernel is instantiated in smhip_side.hip (one group per translation unit, -DSM_SIDE_GROUP=<g>) or, the
 // static-plan transforms, in smhip_inst.hip; smhip_hip.hip holds host code only.  The build parallelises and a
 // change to the host orchestration does not recompile a single kernel.
-#define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
+#define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenPart16) X(KAtenPart32) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
 #define SM_SIDE_KERNELS_1(X) X(KF2R1) X(KI1R1) X(KPublish) X(KHist) X(KScan) X(KSelect2) X(KSelect2Cull) X(KBlendSel) \
     X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials) X(KClassEmf)
 #define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
@@ -1462,8 +1464,14 @@ class Pipeline {
             AtenPartParams b;
             b.nsig = nsig; b.nchunks = nchunks; b.prefix = pre; b.rec = rec; b.grp = grp; b.epred = epred;
             for (int i = 0; i < ATEN_MAX_SIGS; ++i) b.src[i] = srcs[i < nsig ? i : 0];
-            if (kind) be.template launch<KAtenPartC>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
-            else be.template launch<KAtenPart>((int)(nchunks * nsig), ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4, b, stream);
+            int mode = aten_part_mode(srcs[0]);
+            for (int i = 1; i < nsig; ++i) if (aten_part_mode(srcs[i]) != mode || srcs[i].sig.dtype != srcs[0].sig.dtype) mode = kind ? ATEN_PART_CLASS : ATEN_PART_SIGNAL;
+            const int pgrid = (int)(nchunks * nsig);
+            const size_t plds = (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4;
+            if (mode == ATEN_PART_RAW16) be.template launch<KAtenPart16>(pgrid, ATEN_THREADS, plds, b, stream);
+            else if (mode == ATEN_PART_RAW32) be.template launch<KAtenPart32>(pgrid, ATEN_THREADS, plds, b, stream);
+            else if (mode == ATEN_PART_CLASS) be.template launch<KAtenPartC>(pgrid, ATEN_THREADS, plds, b, stream);
+            else be.template launch<KAtenPart>(pgrid, ATEN_THREADS, plds, b, stream);
         }
         void* const main_stream = stream;
         struct StreamSwap { void*& s; void* keep; ~StreamSwap() { s = keep; } } swap_back{stream, main_stream};
