@@ -9,7 +9,7 @@
 // K >= 3 tournament - it does not: 6 % of random 1 K-element vectors differ), adds the lanes in order,
 // then the T = n % 8 tail elements one by one - the first 4 * (T / 4) as a rounded product and an add,
 // the rest as fma: what GCC made of the scalar loop in torch 2.10's AVX2 kernel, established on
-// 510 random vectors (tools/aten_norm_model_check.py) - and takes the square root.  Once a lane's running sum S is large the adds lose low bits:
+// 300 random vectors (oracle/aten_norm_model_probe.py) - and takes the square root.  Once a lane's running sum S is large the adds lose low bits:
 // -7e-4 at 16 M elements, -5e-3 at 67 M (oracle/norm_bias_probe.py), and the reference's
 // pick-the-larger decisions follow the BIASED norms.
 //
@@ -50,7 +50,7 @@
 // the bias is a statistical property of the values: emulating the sum over our planes (a bin that
 // stands for itself and its conjugate twin is added twice, bins outside the class add an exact
 // zero) reproduces the reference's norms to 2e-6 where exact norms are off by 2e-4 (4096^2;
-// tools/aten_norm_model_check.py).
+// oracle/aten_norm_model_probe.py).
 #pragma once
 #include "sm_kernels.hpp"
 
@@ -364,7 +364,8 @@ SM_HD void aten_acc_add2(AtenAcc& coarse, AtenAcc& fine, float x, double scale_f
 // The chunk goes through LDS in ATEN_STAGES stages of 8 rows per thread: the loads are coalesced (8
 // consecutive threads fetch 8 consecutive rows), each thread then reads ITS 8 rows back - a thread's
 // rows must be consecutive for its summary to mean anything.
-constexpr double ATEN_LAG_MARGIN = 0.2;         // how far below the estimated prefix the running sum is allowed for
+constexpr double ATEN_LAG_MARGIN = 0.08;        // how far below the estimated prefix the running sum is allowed for (its bias is
+                                                // -3 % of the sum at 235 M elements; beyond the margin a chunk is walked cooperatively)
 constexpr double ATEN_LEAD_MARGIN = 0.02;       // ... and how far above (lattice data round UP on balance; the estimate
                                                 // comes from a sample)
 constexpr int ATEN_STAGE_ROWS = 8;
@@ -883,7 +884,7 @@ SM_HD void k_aten_finish(Ex& ex, const AtenFinishParams& p) {
 //     G(rho) = rho * sum_{k>=0} erfc(sqrt((k + 1/2) rho / 2))     (= E[rne(y / u)] u / sigma^2),
 // so a lane's sum follows  dS/di = sigma^2 G(ulp(S) / sigma^2)  binade by binade.  Against
 // torch.norm on Gaussian data: -5.420e-3 vs -5.429e-3 at 67 M elements, and on a real K = 3
-// intermediate (4096^2) -6.89e-4 vs -6.97e-4 (tools/aten_norm_model_check.py).
+// intermediate (4096^2) -6.89e-4 vs -6.97e-4 (oracle/aten_norm_model_probe.py).
 inline double aten_gauss_G(double rho) {
     if (rho <= 1.0) {
         // the midpoint sum of h(y) = erfc(sqrt(y / 2)) = 1 - sqrt(2/pi) sum_j (-1)^j y^(j+1/2) / (2^j j! (2j+1)) with

@@ -2257,7 +2257,7 @@ struct SlerpConstParams {
 // k_class_emf takes g for EMF_LEVELS consecutive binades (and the exact mean) from a sample of the planes (all of
 // them below 4 M elements, 1 piece in 16 from 64 M on); k_slerp_consts integrates the trajectory for cnt / 8 elements per lane and scales the exact norm by the
 // ratio.  Against torch.norm on the reference's own gathered vectors: 1e-6 ... 4e-6 where the exact norm is off by
-// 2e-4 (4096^2; tools/aten_norm_model_check.py); the ordered emulation of sm_aten_norm.hpp (test hook
+// 2e-4 (4096^2; oracle/aten_norm_model_probe.py); the ordered emulation of sm_aten_norm.hpp (test hook
 // "class_norms" = 2) gives the same to 2e-6.
 constexpr int EMF_LEVELS = 16;
 constexpr int EMF_VALS = EMF_LEVELS + 2;        // weighted count, sum of squares, EMF_LEVELS sums of rounded squares

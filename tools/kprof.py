@@ -21,23 +21,24 @@ shape = (cols,) if rows == 1 else (rows, cols)
 base = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
 fts = [(base.float() + torch.randn(shape, generator=g, device="cuda") * s).to(torch.bfloat16) for s in (0.002, 0.003, 0.0025, 0.004)[:k]]
 alphas = (0.3, 0.5, 0.2, 0.4)[:k]
-eng.merge_layer(fts, [base] * k, alphas, base)
+mode = os.environ.get("KPROF_NORM_MODE", "reference_cpu")          # the mode bench.py measures; "exact" for the other
+eng.merge_layer(fts, [base] * k, alphas, base, norm_mode=mode)
 torch.cuda.synchronize()
 import time
 t0 = time.time()
 for _ in range(reps):
-    eng.merge_layer(fts, [base] * k, alphas, base)
+    eng.merge_layer(fts, [base] * k, alphas, base, norm_mode=mode)
 torch.cuda.synchronize()
 wall = (time.time() - t0) / reps * 1e3
 eng.ctx.profile(True); eng.ctx.profile_reset()
 for _ in range(reps):
-    eng.merge_layer(fts, [base] * k, alphas, base)
+    eng.merge_layer(fts, [base] * k, alphas, base, norm_mode=mode)
 torch.cuda.synchronize()
 tab = eng.ctx.profile_table()
 eng.ctx.profile(False)
 n = rows * cols
 tot = sum(ms for _, ms in tab.values()) / reps
-print(f"[{rows}x{cols}] K={k}: wall {wall:.3f} ms/layer (unprofiled), sum of kernels {tot:.3f} ms, "
+print(f"[{rows}x{cols}] K={k} norm_mode={mode}: wall {wall:.3f} ms/layer (unprofiled), sum of kernels {tot:.3f} ms, "
       f"merged {2*n/wall/1e6:.1f} GB/s, pipeline frac {({2:60,3:122,4:182}[k])*n/(wall*1e-3)/8e12:.3f}")
 for name, (cnt, ms) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
     print(f"  {name:16s} launches/layer {cnt/reps:5.1f}  {ms/reps:8.3f} ms/layer  {ms/cnt*1e3:9.1f} us/launch")
