@@ -368,10 +368,16 @@ constexpr double ATEN_LAG_MARGIN = 0.08;        // how far below the estimated p
                                                 // -3 % of the sum at 235 M elements; beyond the margin a chunk is walked cooperatively)
 constexpr double ATEN_LEAD_MARGIN = 0.02;       // ... and how far above (lattice data round UP on balance; the estimate
                                                 // comes from a sample)
-constexpr int ATEN_STAGE_ROWS = 8;
+#ifndef SM_ATEN_STAGE_ROWS
+#define SM_ATEN_STAGE_ROWS 4
+#endif
+constexpr int ATEN_STAGE_ROWS = SM_ATEN_STAGE_ROWS;
 constexpr int ATEN_STAGES = ATEN_ROWS_PER_THREAD / ATEN_STAGE_ROWS;
 constexpr int ATEN_STAGE_PITCH = ATEN_STAGE_ROWS * 8 + 4;          // floats per thread: 256 B + 16 B (bank spread)
-constexpr size_t ATEN_PART_LDS_FLOATS = (size_t)ATEN_THREADS * ATEN_STAGE_PITCH + ATEN_THREADS * ATEN_STAGE_ROWS / 4 + 64;
+constexpr size_t ATEN_PART_TREE_FLOATS = (size_t)(9 * ATEN_THREADS + 8 * 32) * 4;      // the composition tree reuses the stage area
+constexpr size_t ATEN_PART_STAGE_FLOATS = (size_t)ATEN_THREADS * ATEN_STAGE_PITCH;
+constexpr size_t ATEN_PART_LDS_FLOATS = (ATEN_PART_STAGE_FLOATS > ATEN_PART_TREE_FLOATS ? ATEN_PART_STAGE_FLOATS : ATEN_PART_TREE_FLOATS)
+                                        + ATEN_THREADS * ATEN_STAGE_ROWS / 4 + 64;
 // the prefetched rows stay RAW (two 16-byte vectors per row: a 16-bit delta's finetune and base pieces, or the two
 // halves of an fp32 row) and are decoded when they go to LDS: a load whose result is branched on (dtype, "has a
 // base", "row exists") is waited for on the spot - the addresses are clamped instead and all loads of a stage issue
@@ -404,7 +410,7 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     const WeightRanges wr = weight_ranges(s.R, s.C, s.Cb);
     const float thr = (KIND == 1 && s.thr) ? *s.thr : 0.f;
     float* stage = ex.lds() + LDS_SCRATCH_FLOATS;                   // [256 threads][8 rows][8] (+ pad)
-    uint8_t* w2row = (uint8_t*)(stage + (size_t)ATEN_THREADS * ATEN_STAGE_PITCH);      // [2048]: a row's "counts twice" bits
+    uint8_t* w2row = (uint8_t*)(stage + (ATEN_PART_LDS_FLOATS - ATEN_THREADS * ATEN_STAGE_ROWS / 4 - 64));      // a row's "counts twice" bits
     AtenSum* ent = (AtenSum*)stage;                                 // after the stages: [256 threads][8 lanes + 1 pad]
     AtenSum* seg = ent + 9 * ATEN_THREADS;                          // [32 groups][8 lanes]
     const size_t slot = ((size_t)sig * p.nchunks + chunk) * 8;
@@ -418,11 +424,11 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
         if (ep[l] == ATEN_NO_EXP || aten_exp_of(before * (1.0 - ATEN_LAG_MARGIN)) != ep[l]) two |= 1u << l;
     }
     const size_t row0 = chunk * ATEN_CHUNK_ROWS;
-    // stage `sidx`: this thread fetches rows q = i * 256 + tid of it (owner q / 8, the owner's row q % 8): 8
-    // consecutive threads read 8 consecutive rows
+    // stage `sidx`: this thread fetches rows q = i * 256 + tid of it (owner q / ATEN_STAGE_ROWS, the owner's row
+    // q % ATEN_STAGE_ROWS): consecutive threads read consecutive rows
     auto stage_row = [&](int tid, int sidx, int i) -> size_t {
         const int qq = i * ATEN_THREADS + tid;
-        return row0 + (size_t)(qq / 8) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (qq % 8);
+        return row0 + (size_t)(qq / ATEN_STAGE_ROWS) * ATEN_ROWS_PER_THREAD + sidx * ATEN_STAGE_ROWS + (qq % ATEN_STAGE_ROWS);
     };
     auto fetch = [&](int tid, AtenPartState& q, int sidx) {
         if constexpr (raw16) {
@@ -484,7 +490,7 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
                     for (int e = 0; e < 8; ++e) v[e] = q.b.pf[i][e];
                     w2bits = q.b.pw[i];
                 }
-                float* d = stage + (size_t)(qq / 8) * ATEN_STAGE_PITCH + (qq % 8) * 8;
+                float* d = stage + (size_t)(qq / ATEN_STAGE_ROWS) * ATEN_STAGE_PITCH + (qq % ATEN_STAGE_ROWS) * 8;
                 cf4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
                 ((cf4*)d)[0] = lo; ((cf4*)d)[1] = hi;
                 if (KIND == 1) w2row[qq] = (uint8_t)w2bits;
@@ -502,7 +508,7 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
             for (int k = 0; k < ATEN_STAGE_ROWS; ++k) {
                 const cf4 lo = ((const cf4*)(src + k * 8))[0], hi = ((const cf4*)(src + k * 8))[1];
                 const float y[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const uint32_t w2 = KIND == 1 ? w2row[tid * 8 + k] : 0u;
+                const uint32_t w2 = KIND == 1 ? w2row[tid * ATEN_STAGE_ROWS + k] : 0u;
 #pragma unroll
                 for (int l = 0; l < 8; ++l) {
                     const int reps = ((w2 >> l) & 1u) ? 2 : 1;

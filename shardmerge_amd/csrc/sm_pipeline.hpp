@@ -176,8 +176,11 @@ SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
 SM_KERNEL_TAG_LB(KAtenPre, AtenPreParams, "aten_norm_pre", k_aten_pre<0>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenPreC, AtenPreParams, "aten_norm_pre", k_aten_pre<1>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenScan, AtenScanParams, "aten_norm_scan", k_aten_scan(ex, p), 256, 4)
-SM_KERNEL_TAG_LB(KAtenPart16, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW16>(ex, p), 256, 2)   // 16 running summaries per thread
-SM_KERNEL_TAG_LB(KAtenPart32, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW32>(ex, p), 256, 2)
+#ifndef SM_ATEN_PART_WAVES
+#define SM_ATEN_PART_WAVES 3
+#endif
+SM_KERNEL_TAG_LB(KAtenPart16, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW16>(ex, p), 256, SM_ATEN_PART_WAVES)   // 16 running summaries per thread
+SM_KERNEL_TAG_LB(KAtenPart32, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_RAW32>(ex, p), 256, SM_ATEN_PART_WAVES)
 SM_KERNEL_TAG_LB(KAtenPart, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_SIGNAL>(ex, p), 256, 2)
 SM_KERNEL_TAG_LB(KAtenPartC, AtenPartParams, "aten_norm_part", k_aten_part<ATEN_PART_CLASS>(ex, p), 256, 2)
 SM_KERNEL_TAG_LB(KAtenWalk, AtenWalkParams, "aten_norm_walk", k_aten_walk<0>(ex, p), 256, 4)
