@@ -684,12 +684,60 @@ SM_HD void k_aten_walk(Ex& ex, const AtenWalkParams& p) {
             ex.sync();
         }
         ex.each(st, [&](int tid, AtenWalkState&) {
-            for (int j = tid; j < nrows; j += ATEN_THREADS) {               // coalesced
-                const size_t r = r0 + (size_t)j;
-                bool twice = false;
-                const float y = r < rows ? aten_load_one<KIND>(s, wr, thr, r, lane, twice) : 0.f;
-                ybuf[(j / ATEN_ROWS_PER_THREAD) * ATEN_YPITCH + (j % ATEN_ROWS_PER_THREAD)] = y;
-                if (twice) ex.lds_atomic_add(&wbits[j / ATEN_ROWS_PER_THREAD], 1u << (j % ATEN_ROWS_PER_THREAD));
+            // (8 loads in flight at a time, from clamped addresses: a load behind the "row exists" test would be waited for
+            // on the spot - 32 of them in a row for a whole chunk)
+            for (int j0 = tid; j0 < nrows; j0 += 8 * ATEN_THREADS) {        // coalesced
+                float y[8];
+                bool twice[8];
+                size_t idx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t r = r0 + (size_t)(j0 + u * ATEN_THREADS);
+                    idx[u] = (r < rows ? r : rows - 1) * 8 + lane;
+                    twice[u] = false;
+                }
+                if (KIND == 0 && s.sig.dtype == DT_F32) {                   // (the dtype test outside the loads: see above)
+                    const float* X = (const float*)s.sig.x;
+                    const float* B = (const float*)s.sig.base;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = X[idx[u]];
+                    if (B) {
+                        float b[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) b[u] = B[idx[u]];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) y[u] -= b[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] *= s.sig.prescale;
+                } else if (KIND == 0) {
+                    const uint16_t* X = (const uint16_t*)s.sig.x;
+                    const uint16_t* B = (const uint16_t*)s.sig.base;
+                    uint32_t xv[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = X[idx[u]];
+                    if (B) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) bv[u] = B[idx[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float xf = s.sig.dtype == DT_BF16 ? bf16_to_f(xv[u]) : f16_to_f(xv[u]);
+                        const float bf = B ? (s.sig.dtype == DT_BF16 ? bf16_to_f(bv[u]) : f16_to_f(bv[u])) : 0.f;
+                        y[u] = (xf - bf) * s.sig.prescale;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = aten_load_one<KIND>(s, wr, thr, idx[u] / 8, lane, twice[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * ATEN_THREADS;
+                    if (j >= nrows) break;
+                    const bool live = r0 + (size_t)j < rows;
+                    ybuf[(j / ATEN_ROWS_PER_THREAD) * ATEN_YPITCH + (j % ATEN_ROWS_PER_THREAD)] = live ? y[u] : 0.f;
+                    if (live && twice[u]) ex.lds_atomic_add(&wbits[j / ATEN_ROWS_PER_THREAD], 1u << (j % ATEN_ROWS_PER_THREAD));
+                }
             }
         });
         ex.sync();

@@ -1119,7 +1119,8 @@ class Pipeline {
                 q.sample = 1;
                 while (q.sample < EMF_MAX_SAMPLE && q.n / (2 * (size_t)q.sample) >= EMF_MIN_SAMPLED) q.sample *= 2;
                 const size_t rows = (q.n + 7) / 8, npieces = (rows + 8 * (size_t)q.sample - 1) / (8 * (size_t)q.sample);
-                q.iters = (int)std::max<size_t>(1, std::min<size_t>(64, npieces / ((size_t)32 * 1024)));
+                q.iters = (int)std::max<size_t>(1, std::min<size_t>(64, (npieces + (size_t)32 * 384 - 1) / ((size_t)32 * 384)));   // ~384 work-groups: their
+                                                                         // 36-value partials are summed by ONE work-group (k_slerp_consts)
                 const int grid = (int)std::max<size_t>(1, (npieces + (size_t)32 * q.iters - 1) / ((size_t)32 * q.iters));
                 if (!ensure(emf_, (size_t)grid * 2 * EMF_VALS * sizeof(double))) {
                     q.partials = (double*)emf_.p;
