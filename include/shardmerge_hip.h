@@ -61,7 +61,11 @@ int smhip_length_supported(int n);
 /* 0 if smhip_merge_layer takes a [rows x cols] tensor (rows = 1 for 1-D): one length must have a
  * plan; the other may also be p * M with M planned and even and p <= 256 - 11008 = 43 * 256,
  * 18944 = 37 * 512, 65536 = 2 * 32768, 128256 = 167 * 768 - which costs one extra pass over the
- * row spectra each way (and, when it is the ROW length, a transpose of the operands). */
+ * row spectra each way (and, when it is the ROW length, a transpose of the operands).  A tensor without
+ * any planned length (Falcon-7B: 4544 = 71 * 64, 4672 = 73 * 64) is taken when one length splits as
+ * above and the other, of any factorisation and parity, is <= 16384: its rows go through the chirp-z
+ * row passes (sm_bluestein.hpp), 3-4x the arithmetic of a planned length.  The function-level entry
+ * points A4-A10 take such a ROW length too (their column length needs a plan). */
 int smhip_shape_supported(int rows, int cols);
 
 /* ---- A4 / A8: transforms (reference fft_transform / ifft_transform,
@@ -176,6 +180,8 @@ int smhip_reference_cpu_norm(smhip_ctx* ctx, const void* x, const void* base, in
  *      "sel_chunks" sets the steps per thread of the level-2 selection pass,
  *      "force_split" = p splits the column length of smhip_merge_layer into p row blocks (the path of
  *      lengths without a plan, smhip_shape_supported) although it has one, 0 = off;
+ *      "force_bluestein" = 1 sends every row transform through the chirp-z row passes (the path of ROW lengths
+ *      without a plan);
  *      "pair1d" = 0 sends 1-D tensors through the multi-kernel pipeline instead of the one-launch pair merge;
  *      "spec_cull" = 0 keeps the SLERP blend and the cull's selection pass apart (no speculation on the
  *      threshold's level-1 bin); "spec_min_bins" = the smallest spectrum (bins) that speculates (default 2^20);

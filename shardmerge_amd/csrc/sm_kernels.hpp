@@ -799,15 +799,18 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
                 for (int q = 0; q < EMAX / 2; ++q) {
                     const int m = lane + (q / ILV) * 2 * T;               // row group
                     const int n = m * ILV + q % ILV;
-                    cf4 v = {0.f, 0.f, 0.f, 0.f};
+                    // (clamped address, masked value: see k_f2s)
+                    const bool live = n < R && k2 < p.Cb;
+                    const int kc = k2 < p.Cb ? k2 : p.Cb - 1;
+                    const int mcl = n < R ? m : (R - 1 - q % ILV) / ILV;
+                    cf4 v;
                     if constexpr (FOLD) {
                         // slab-major T1: virtual column k2 = (k1, bin) lives in slab k1, row pitch = slab
-                        if (n < R && k2 < p.Cb)
-                            v = t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)m * p.slab + (k2 % p.slab)) * ILV + q % ILV];
+                        v = t1[(size_t)(kc / p.slab) * p.slab_elems + ((size_t)mcl * p.slab + (kc % p.slab)) * ILV + q % ILV];
                     } else {
-                        if (n < R && k2 < p.Cb) v = t1[((size_t)m * p.pitch4 + k2) * ILV + q % ILV];
+                        v = t1[((size_t)mcl * p.pitch4 + kc) * ILV + q % ILV];
                     }
-                    s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
+                    s.xr[2 * q] = live ? v.x : 0.f; s.xi[2 * q] = live ? v.y : 0.f; s.xr[2 * q + 1] = live ? v.z : 0.f; s.xi[2 * q + 1] = live ? v.w : 0.f;
                 }
             };
             if (ilv == 2) load_rows(std::integral_constant<int, 2>{});
@@ -1007,14 +1010,17 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
 #pragma unroll
         for (int q = 0; q < EMAX / 2; ++q) {
             const int m = F2S_ILV * (lane + (q / F2S_ILV) * T) + q % F2S_ILV;      // row pair (rows 2m, 2m+1)
-            cf4 v = {0.f, 0.f, 0.f, 0.f};
+            // (the address is clamped, the value masked afterwards: behind a branch every load is waited for on the
+            // spot - the 7168-point plan, whose last two slots are empty, ran its 14 strided loads one after the other)
+            const bool live = m < half && k2 < p.Cb;
+            const int mc = m < half ? m : half - 1, kc = k2 < p.Cb ? k2 : p.Cb - 1;
+            cf4 v;
             if constexpr (FOLD) {
-                if (m < half && k2 < p.Cb)
-                    v = t1[(size_t)(k2 / p.slab) * p.slab_elems + ((size_t)(m / F2S_ILV) * p.slab + (k2 % p.slab)) * F2S_ILV + m % F2S_ILV];
+                v = t1[(size_t)(kc / p.slab) * p.slab_elems + ((size_t)(mc / F2S_ILV) * p.slab + (kc % p.slab)) * F2S_ILV + mc % F2S_ILV];
             } else {
-                if (m < half && k2 < p.Cb) v = t1[((size_t)(m / F2S_ILV) * p.pitch4 + k2) * F2S_ILV + m % F2S_ILV];
+                v = t1[((size_t)(mc / F2S_ILV) * p.pitch4 + kc) * F2S_ILV + mc % F2S_ILV];
             }
-            s.xr[2 * q] = v.x; s.xi[2 * q] = v.y; s.xr[2 * q + 1] = v.z; s.xi[2 * q + 1] = v.w;
+            s.xr[2 * q] = live ? v.x : 0.f; s.xi[2 * q] = live ? v.y : 0.f; s.xr[2 * q + 1] = live ? v.z : 0.f; s.xi[2 * q + 1] = live ? v.w : 0.f;
         }
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });

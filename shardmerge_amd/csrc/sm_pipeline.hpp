@@ -14,6 +14,7 @@
 #include "../../include/shardmerge_hip.h"
 #include "sm_kernels.hpp"
 #include "sm_aten_norm.hpp"
+#include "sm_bluestein.hpp"
 
 namespace smhip {
 
@@ -63,11 +64,25 @@ SM_FFT_KERNEL_TAG(KF2Q, F2Params, "f2_cols_fwd", (k_f2<P, f2_bins<P>(), true>(ex
 SM_FFT_KERNEL_TAG(KF2SQ, F2SParams, "f2s_cols_fwd1", (k_f2s<P, f2s_groups<P>(), true>(ex, p)), f2s_groups<P>(), 4)
 SM_FFT_KERNEL_TAG(KI1x1Q, I1Params, "i1_cols_inv", (k_i1<P, 1, true>(ex, p)), 1, 4)
 SM_FFT_KERNEL_TAG(KI1x2Q, I1Params, "i1_cols_inv", (k_i1<P, i1_bins<P>(), true>(ex, p)), i1_bins<P>(), 4)
+// row passes of a row length without a plan (sm_bluestein.hpp); P is the plan of the convolution length
+// (one transform per work-group and two of them back to back: compiled for two waves per SIMD - 256 VGPRs - where
+//  the work-group allows it; at 128 the 16384-point convolution kept 700 bytes per lane in scratch)
+#define SM_BLUE_KERNEL_TAG(Tag, ParamsT, NAME, CALL)                                 \
+    template <class P> struct Tag {                                                  \
+        using Params = ParamsT;                                                      \
+        static constexpr int max_threads = fft_max_threads<P, 1>();                  \
+        static constexpr int waves = max_threads > 512 ? 4 : 2;                      \
+        static const char* name() { return NAME; }                                   \
+        template <class Ex> static SM_HD void run(Ex& ex, const Params& p) { CALL; } \
+    };
+SM_BLUE_KERNEL_TAG(KF1B, F1BParams, "f1_rows_fwd", k_f1b<P>(ex, p))
+SM_BLUE_KERNEL_TAG(KI2B, I2BParams, "i2_rows_inv", k_i2b<P>(ex, p))
 SM_FFT_KERNEL_TAG(KPair1d, Pair1dParams, "pair_1d", k_pair1d<P>(ex, p), 1, 1)      // one work-group per launch: all the registers it wants
 
 // lengths that get straight-line kernels (powers of two, the 7 * 2^k of Llama-3 / Mixtral MLPs,
 // the 3/5/7 * 2^k hidden and MLP sizes of other common models, and 256 / 512: the row blocks of the
-// split column lengths 11008 = 43 * 256 (Llama-2-7B) and 18944 = 37 * 512 (Qwen2-7B): a run-time planned length
+// split column lengths 11008 = 43 * 256 (Llama-2-7B), 18944 = 37 * 512 (Qwen2-7B), 4544 = 71 * 64 and 4672 = 73 * 64
+// (Falcon-7B: as run-time plans its 64-point blocks took 9 + 12 ms per 4544^2 pair merge): a run-time planned length
 // runs the same code with its register arrays in scratch memory, 5120^2: 5.4 ms against 0.7);
 // must agree with plan_shape() below
 // (checked at dispatch: a mismatch silently falls back to the DynPlan kernel)
@@ -109,7 +124,9 @@ SM_FFT_KERNEL_TAG(KPair1d, Pair1dParams, "pair_1d", k_pair1d<P>(ex, p), 1, 1)   
     X(SPlan<27648, 1024, false, 4, 32, 32, 3, 3, 3>) \
     X(SPlan<2304, 128, false, 4, 16, 16, 3, 3>) \
     X(SPlan<256, 64, false, 4, 8, 8, 4>)            \
-    X(SPlan<512, 64, false, 4, 32, 16>)
+    X(SPlan<512, 64, false, 4, 32, 16>)             \
+    X(SPlan<64, 64, false, 4, 8, 8>)                \
+    X(SPlan<128, 64, false, 4, 16, 8>)
 
 // measured on MI355X (8192^2): the complex exchange halves occupancy and brings spills back -
 // 1.6x slower than split exchanges, so no plan uses it for now
@@ -195,7 +212,7 @@ SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finis
 #define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
     X(KCull) X(KAddition) X(KCorrPartial) X(KCorrFinish) X(KSerialNorm) X(KSpecNorm) X(KSumsqCand) X(KSumSpec)       \
     X(KSpecRescale) X(KDftp) X(KDftpPairs) X(KTranspose)
-#define SM_SIDE_GROUPS 6         // groups 3, 4, 5: the run-time planned (DynPlan) transform kernels
+#define SM_SIDE_GROUPS 7         // groups 3 - 6: the run-time planned (DynPlan) transform kernels
 
 // ---- FFT planner ---------------------------------------------------------------
 struct HostPlan {
@@ -251,8 +268,17 @@ inline bool rough_split(int N, int& p, int& M) {
     }
     return false;
 }
-// [rows x cols] as the layer merge takes it: the row length must be planned; the column length may
-// be split (rough_split); a tensor that fits only the other way round is merged transposed
+// A ROW length the engine cannot plan: Bluestein's convolution on a power-of-two plan of L >= 2C - 1
+// points (sm_bluestein.hpp).  0: too long.
+inline int bluestein_len(int C) {
+    if (C < 2) return 0;
+    for (int L = 256; L <= EMAX * 1024; L *= 2)
+        if (L >= 2 * C - 1) return L;
+    return 0;
+}
+// [rows x cols] as the layer merge takes it: the row length wants a plan; the column length may
+// be split (rough_split); a tensor that fits only the other way round is merged transposed; one whose
+// lengths are both rough has its rows transformed by k_f1b / k_i2b
 inline int shape_support(int rows, int cols, bool* transposed = nullptr) {
     int T, p, M;
     std::vector<int> rad;
@@ -260,6 +286,8 @@ inline int shape_support(int rows, int cols, bool* transposed = nullptr) {
     if (rows < 1 || cols < 1) return 0;
     if (plan_shape(cols, T, rad) && rough_split(rows, p, M)) return 1;
     if (plan_shape(rows, T, rad) && rough_split(cols, p, M)) { if (transposed) *transposed = true; return 1; }
+    if (bluestein_len(cols) && rough_split(rows, p, M)) return 1;
+    if (bluestein_len(rows) && rough_split(cols, p, M)) { if (transposed) *transposed = true; return 1; }
     return 0;
 }
 
@@ -309,6 +337,7 @@ class Pipeline {
         for (Buffer& b : rowspec_) if (b.p) be.free(b.p);
         for (Buffer& b : tr_) if (b.p) be.free(b.p);
         for (auto& kv : rough_tw_) if (kv.second) be.free(kv.second);
+        for (auto& kv : blue_) { if (kv.second.chirp) be.free(kv.second.chirp); if (kv.second.filt) be.free(kv.second.filt); }
     }
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
@@ -399,7 +428,7 @@ class Pipeline {
         Geo g;
         g.R = R; g.C = C; g.full = full;
         g.batch = batch < 1 ? 1 : batch;
-        g.fold = (allow_fold && fold_enabled && !full && g.batch == 1 && fold_shape(R, C)) ? 4 : 1;
+        g.fold = (allow_fold && fold_enabled && !full && g.batch == 1 && fold_shape(R, C) && !row_bluestein(C)) ? 4 : 1;
         g.Cb = full ? C : (C / 2 + 1) * g.batch;
         g.pitch4 = (int)round_up((size_t)(C / 2 + 1), 8);
         g.t1_slice = round_up((size_t)R, 8) * (size_t)g.pitch4;
@@ -538,6 +567,76 @@ class Pipeline {
     static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
     static int vec4(const Geo& g) { return g.full ? (((size_t)g.R * g.C) % 4 == 0) : (g.R % 4 == 0); }
 
+    // ---- a row length without a plan: Bluestein's convolution (sm_bluestein.hpp) ------------------
+    bool debug_force_bluestein = false;      // test hook: k_f1b / k_i2b for planned row lengths too
+    bool row_bluestein(int C) const {
+        int T; std::vector<int> rad;
+        if (debug_force_bluestein) return bluestein_len(C) > 0;
+        return !plan_shape(C, T, rad) && bluestein_len(C) > 0;
+    }
+    struct BlueHost { void* chirp = nullptr; void* filt = nullptr; int L = 0; };
+    // chirp[n] = exp(-i pi n^2 / C) and the spectrum of the convolution's filter, both from double precision
+    int bluestein_tables(int C, BluesteinTab& out, FftPlanDev& plan) {
+        const int L = bluestein_len(C);
+        if (!L) return fail(SMHIP_ERR_SHAPE, "row length too long for the chirp-z transform");
+        int rc = get_plan(L, plan);
+        if (rc) return rc;
+        auto it = blue_.find(C);
+        if (it == blue_.end()) {
+            std::vector<double> wr(C), wi(C);
+            for (int n = 0; n < C; ++n) {
+                const unsigned long long m = ((unsigned long long)n * (unsigned long long)n) % (2ull * (unsigned long long)C);
+                const double ang = -M_PI * (double)m / (double)C;
+                wr[n] = cos(ang); wi[n] = sin(ang);
+            }
+            std::vector<double> hr(L, 0.0), hi(L, 0.0);
+            for (int m = 0; m < C; ++m) {
+                hr[m] = wr[m]; hi[m] = -wi[m];
+                if (m) { hr[L - m] = wr[m]; hi[L - m] = -wi[m]; }
+            }
+            // radix-2 transform of the filter on the host (L is a power of two)
+            for (int i = 1, j = 0; i < L; ++i) {
+                int bit = L >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) { std::swap(hr[i], hr[j]); std::swap(hi[i], hi[j]); }
+            }
+            for (int len = 2; len <= L; len <<= 1) {
+                const int half = len / 2;
+                for (int k = 0; k < half; ++k) {
+                    const double ang = -2.0 * M_PI * (double)k / (double)len;
+                    const double cr = cos(ang), ci = sin(ang);
+                    for (int i = k; i < L; i += len) {
+                        const int j = i + half;
+                        const double tr = hr[j] * cr - hi[j] * ci, ti = hr[j] * ci + hi[j] * cr;
+                        hr[j] = hr[i] - tr; hi[j] = hi[i] - ti;
+                        hr[i] += tr; hi[i] += ti;
+                    }
+                }
+            }
+            std::vector<cf2> chirp(C), filt(L);
+            for (int n = 0; n < C; ++n) { chirp[n].x = (float)wr[n]; chirp[n].y = (float)wi[n]; }
+            for (int k = 0; k < L; ++k) { filt[k].x = (float)(hr[k] / L); filt[k].y = (float)(hi[k] / L); }
+            BlueHost bh;
+            bh.L = L;
+            bh.chirp = be.alloc(sizeof(cf2) * C);
+            bh.filt = be.alloc(sizeof(cf2) * L);
+            if (!bh.chirp || !bh.filt) return fail(SMHIP_ERR_NOMEM, "chirp table alloc failed");
+            be.h2d(bh.chirp, chirp.data(), sizeof(cf2) * C, stream);
+            be.h2d(bh.filt, filt.data(), sizeof(cf2) * L, stream);
+            be.sync(stream);                       // the host vectors die here
+            it = blue_.emplace(C, bh).first;
+        }
+        out.chirp = (const cf2*)it->second.chirp; out.filt = (const cf2*)it->second.filt;
+        return SMHIP_OK;
+    }
+    // the row plan of a tensor: its own, or the convolution's
+    int get_row_plan(int C, FftPlanDev& plan, bool& blue, BluesteinTab& bt) {
+        blue = row_bluestein(C);
+        bt.chirp = nullptr; bt.filt = nullptr;
+        return blue ? bluestein_tables(C, bt, plan) : get_plan(C, plan);
+    }
+
     // exp(-2 pi i j / N) for a length without a plan (k_dftp's twiddles)
     int rough_twiddles(int N, const cf2** out) {
         auto it = rough_tw_.find(N);
@@ -581,12 +680,13 @@ class Pipeline {
     // F1: T1 <- row spectra of (a, b); per-group sums of squares land in d_part()
     int run_f1(const Geo& g, const SigDesc& a, const SigDesc& b, int& grid_out) {
         F1Params p;
-        int rc = get_plan(g.C, p.plan);
+        bool blue; BluesteinTab bt;
+        int rc = get_row_plan(g.C, p.plan, blue, bt);
         if (rc) return rc;
         p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = g.ilv;
-        p.nb = std::max(1, 256 / p.plan.T);
+        p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)g.C;
-        p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
         p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g);
@@ -614,7 +714,8 @@ class Pipeline {
             p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
             p.t1 = (cf4*)t1_.p + (size_t)bi * g.t1_slice;
             p.partials = d_part() + (size_t)bi * 2 * grid;
-            launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+            if (blue) { F1BParams q; q.f = p; q.bt = bt; launch_fft<KF1B>(p.plan, grid, p.plan.T, lds, q); }
+            else launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
         }
         grid_out = grid * nlaunch;
         if (g.rough > 1) return run_dftp(g, t1_.p, false, p.ilv, g.pitch4, g.t1_slice, false);
@@ -637,15 +738,16 @@ class Pipeline {
     static bool joint_rows(const Geo& g) { return g.rough > 1 && g.R % 16 == 0; }
     int run_f1_rowpairs(const Geo& g, const SigDesc& sig, void* t1buf = nullptr, double* partials = nullptr, int* grid_out = nullptr) {
         F1Params p;
-        int rc = get_plan(g.C, p.plan);
+        bool blue; BluesteinTab bt;
+        int rc = get_row_plan(g.C, p.plan, blue, bt);
         if (rc) return rc;
         SigDesc a = sig, b = sig;
         b.x = (const char*)sig.x + (size_t)g.C * dt_size(sig.dtype);
         if (sig.base) b.base = (const char*)sig.base + (size_t)g.C * dt_size(sig.dtype);
         p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = F2S_ILV;
-        p.nb = std::max(1, 256 / p.plan.T);
+        p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)2 * g.C;
-        p.vec = (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
         p.t1 = (cf4*)(t1buf ? t1buf : t1_.p);
         p.partials = partials ? partials : d_part();
         p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g, true);
@@ -672,7 +774,8 @@ class Pipeline {
             p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
             p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
             p.partials = pbase + (size_t)bi * 2 * grid;
-            launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
+            if (blue) { F1BParams q; q.f = p; q.bt = bt; launch_fft<KF1B>(p.plan, grid, p.plan.T, lds, q); }
+            else launch_fft<KF1>(p.plan, grid, p.nb * p.plan.T, lds, p, p.vec != 0);
         }
         if (grid_out) *grid_out = grid * nlaunch;
         if (g.rough > 1) return run_dftp(g, t1base, true, F2S_ILV, g.pitch4, g.t1_slice / 2, false);
@@ -979,10 +1082,11 @@ class Pipeline {
         const int grid1 = (int)round_up((size_t)(Cb + a.s - 1) / a.s, 8 * (16 / a.s));
 
         I2Params b;
-        if ((rc = get_plan(g.C, b.plan))) return rc;
+        bool blue; BluesteinTab bt;
+        if ((rc = get_row_plan(g.C, b.plan, blue, bt))) return rc;
         b.G = (const cf2*)t1_.p; b.pitchG = g.pitchG; b.R = g.R; b.C = g.C; b.Cb = Cb;
-        b.nb = std::max(1, 256 / b.plan.T);
-        b.vec = (g.C % 8 == 0) && aligned16(o.out) && aligned16(o.base);
+        b.nb = blue ? 1 : std::max(1, 256 / b.plan.T);
+        b.vec = !blue && (g.C % 8 == 0) && aligned16(o.out) && aligned16(o.base);
         b.inv_n = (float)(1.0 / ((double)g.R * (double)g.rough * (double)g.C));
         b.ifft_policy = o.ifft_policy;
         b.post = o.post; b.base_dtype = o.base_dtype; b.out_mode = o.out_mode;
@@ -1028,7 +1132,8 @@ class Pipeline {
             b.base = o.base ? (const char*)o.base + bi * eslice * dt_size(o.base_dtype) : nullptr;
             b.out = (char*)o.out + bi * eslice * (o.out_mode == OUT_BF16 ? 2 : 4);
             b.norm_partials = want_norm ? d_part() + (size_t)bi * 2 * grid2 : nullptr;
-            launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
+            if (blue) { I2BParams q; q.i = b; q.bt = bt; launch_fft<KI2B>(b.plan, grid2, b.plan.T, lds2, q); }
+            else launch_fft<KI2>(b.plan, grid2, b.nb * b.plan.T, lds2, b, b.vec != 0);
         }
         }
         return SMHIP_OK;
@@ -1146,7 +1251,7 @@ class Pipeline {
     // ---- a whole SLERP pair merge of 1-D tensors in one launch (k_pair1d) ------------------------------
     bool pair1d_enabled = true;
     bool pair1d_ok(const Geo& g) const {
-        return pair1d_enabled && g.R == 1 && g.batch == 1 && !g.full && g.C >= 2 && g.C <= PAIR1D_MAX_C;
+        return pair1d_enabled && g.R == 1 && g.batch == 1 && !g.full && g.C >= 2 && g.C <= PAIR1D_MAX_C && !row_bluestein(g.C);
     }
     // A = the larger-norm input.  Leaves the thresholds in d_thr(0/1) and the constants in d_consts() as the
     // multi-kernel path does; norm_parts (optional): one [2] partial of the stored values' squares in d_part()
@@ -2155,6 +2260,7 @@ class Pipeline {
     std::vector<Buffer> rowspec_;          // K >= 3: row spectra of the raw deltas (rows_first)
     std::vector<Buffer> tr_;               // transposed copies of a layer's tensors (rough ROW length)
     std::map<int, void*> rough_tw_;        // twiddles of the column lengths without a plan
+    std::map<int, BlueHost> blue_;         // chirp tables of the row lengths without a plan
     std::vector<double> host_part_;
 };
 

@@ -75,6 +75,6 @@ __global__ void __launch_bounds__(K::max_threads, K::waves) sm_kernel(const type
 #define SM_FFT_KERNELS_OF(X, ...)                      \
     X(KF1<__VA_ARGS__>) X(KF2<__VA_ARGS__>) X(KI1x1<__VA_ARGS__>) X(KI1x2<__VA_ARGS__>) X(KI2<__VA_ARGS__>) X(KF2S<__VA_ARGS__>) \
     X(KF1Q<__VA_ARGS__>) X(KF2Q<__VA_ARGS__>) X(KF2SQ<__VA_ARGS__>) X(KI1x1Q<__VA_ARGS__>) X(KI1x2Q<__VA_ARGS__>) \
-    X(KPair1d<__VA_ARGS__>)
+    X(KPair1d<__VA_ARGS__>) X(KF1B<__VA_ARGS__>) X(KI2B<__VA_ARGS__>)
 
 }  // namespace smhip

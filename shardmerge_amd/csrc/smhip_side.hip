@@ -1,5 +1,5 @@
 // smhip_side.hip - explicit instantiation of one group of kernels, selected with -DSM_SIDE_GROUP=<g>
-// (SM_SIDE_KERNELS_<g> in sm_pipeline.hpp; groups 3..5: the transform kernels for run-time planned lengths).
+// (SM_SIDE_KERNELS_<g> in sm_pipeline.hpp; groups 3..6: the transform kernels for run-time planned lengths).
 #include "smhip_device.hpp"
 
 namespace smhip {
@@ -16,7 +16,9 @@ SM_INST(KF1<DynPlan>) SM_INST(KF1Q<DynPlan>) SM_INST(KI2<DynPlan>) SM_INST(KPair
 SM_INST(KF2<DynPlan>) SM_INST(KF2Q<DynPlan>) SM_INST(KF2S<DynPlan>) SM_INST(KF2SQ<DynPlan>)
 #elif SM_SIDE_GROUP == 5
 SM_INST(KI1x1<DynPlan>) SM_INST(KI1x2<DynPlan>) SM_INST(KI1x1Q<DynPlan>) SM_INST(KI1x2Q<DynPlan>)
+#elif SM_SIDE_GROUP == 6
+SM_INST(KF1B<DynPlan>) SM_INST(KI2B<DynPlan>)
 #else
-#error "SM_SIDE_GROUP must be 0..5"
+#error "SM_SIDE_GROUP must be 0..6"
 #endif
 }  // namespace smhip

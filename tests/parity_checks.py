@@ -199,7 +199,8 @@ def check_layer_steps(rep, tr, numel, reported_fields=True, biased_slerp_norms=F
             loose = 100.0 if biased_slerp_norms else 1.0
             assert abs(info.cull_threshold - bt.cull_threshold) <= loose * max(5e-5, gran) * bt.cull_threshold + 1e-30, f"step {i} cull"
             assert abs(info.n_slerp - bt.n_slerp) <= 4 + 1e-4 * bt.n_slerp, f"step {i} n_slerp"
-            assert abs(info.dot - bt.dot) <= loose * 1e-4, f"step {i} dot"
+            # (one bin in or out of the class - a rank shifted through FFT rounding, as above - moves the cosine by ~1/n)
+            assert abs(info.dot - bt.dot) <= loose * max(1e-4, 1.0 / max(numel, 1)), f"step {i} dot"
         else:
             if first_cut:
                 assert info.cutoff_threshold < 1e-3 * first_cut and bt.cutoff_threshold < 1e-3 * first_cut, \

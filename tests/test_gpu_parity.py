@@ -716,6 +716,46 @@ def test_llama2_and_qwen2_mlp_shapes_k2_vs_exact_norm_oracle(engine, shape):
     assert best < 5e-6, f"beyond the tie bins: {best:.2e}"
 
 
+@pytest.mark.parametrize("shape", [(64, 96), (32, 256), (128, 40)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("k", [2, 3])
+def test_chirp_z_row_passes_on_device(engine, shape, k):
+    emul_tier.test_chirp_z_row_passes_agree_with_the_planned_ones(engine, shape, k)
+
+
+@pytest.mark.parametrize("shape", [(34, 38), (68, 76), (142, 142), (172, 86), (34, 17), (17, 32), (17, 128)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("k", [2, 3])
+def test_both_lengths_without_a_plan_on_device(engine, shape, k):
+    emul_tier.test_both_lengths_without_a_plan(engine, shape, k)
+
+
+@pytest.mark.parametrize("shape", [(64, 38), (32, 17), (1, 38), (128, 142)], ids=lambda s: "x".join(map(str, s)))
+def test_function_level_transforms_on_a_rough_row_length_on_device(engine, shape):
+    emul_tier.test_function_level_transforms_on_a_row_length_without_a_plan(engine, shape)
+
+
+@pytest.mark.parametrize("shape,k", [((4544, 4544), 2), ((4672, 4544), 2), ((4544, 4544), 3)], ids=["4544sq_k2", "4672x4544_k2", "4544sq_k3"])
+def test_falcon_7b_shapes_vs_exact_norm_oracle(engine, shape, k):
+    """Falcon-7B's attention tensors at FULL size: 4544 = 71 * 64 and 4672 = 73 * 64, no planned length on either
+    axis - the column length split into row blocks (k_dftp), the rows through the chirp-z row passes (k_f1b / k_i2b).
+    Same bar as the other full-size shapes."""
+    _oracle_threads()
+    rows, cols = shape
+    assert engine.lib.shape_supported(rows, cols) and not engine.lib.length_supported(rows) and not engine.lib.length_supported(cols)
+    base, fts = so.synthetic_layer(rows, cols, k, seed=91 + rows + cols)
+    out, rep, delta = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, want_delta=True, norm_mode="exact")
+    out, delta = out.cpu(), delta.cpu()
+    tr = so.LayerTrace()
+    with so.exact_norms(), so.fast_select():
+        ref = so.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, trace=tr)
+    pc.check_layer_steps(rep, tr, out.numel())
+    if k == 2:
+        d_total, d_resid = pc.spectral_residual(delta, tr.merged_delta, drop=64)
+        assert d_total < 1e-3 and so.rel_err(out.float(), ref.float()) < 1e-3
+        assert d_resid < 5e-6, f"beyond the tie bins: {d_resid:.2e}"
+    else:
+        assert so.rel_err(out.float(), ref.float()) < 5e-3 and so.rel_err(delta, tr.merged_delta) < 8e-2
+
+
 def test_generic_dft_kernel_on_device(engine):
     emul_tier.test_generic_dft_kernel_agrees_with_the_paired_one(engine)
 
