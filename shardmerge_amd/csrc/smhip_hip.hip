@@ -55,7 +55,11 @@ struct HipBackend {
     // stream s does in between, and is complete (in stream order) for everything s does after the join
     void* aux_stream() {
         if (!aux && ok()) {
-            if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; (void)hipGetLastError(); return nullptr; }
+            // highest priority: its few latency-bound work-groups (the norm walker) must get onto the CUs between the row
+            // pass's work-groups, not behind the last of them
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+            if (hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi) != hipSuccess) { aux = nullptr; (void)hipGetLastError(); return nullptr; }
             check(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "hipEventCreate");
             check(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming), "hipEventCreate");
         }
