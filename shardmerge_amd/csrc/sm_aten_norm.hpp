@@ -474,8 +474,9 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
                 uint32_t w2bits = 0u;
                 if constexpr (raw16) {
                     float f[8], bb[8];
-                    decode16x8(q.b.raw[i][0], s.sig.dtype, f);
-                    decode16x8(q.b.raw[i][1], s.sig.dtype, bb);
+                    // (the dtype is uniform: one branch per row instead of a bf16 AND an f16 decode per value with a select)
+                    if (s.sig.dtype == DT_BF16) { decode16x8(q.b.raw[i][0], DT_BF16, f); decode16x8(q.b.raw[i][1], DT_BF16, bb); }
+                    else { decode16x8(q.b.raw[i][0], DT_F16, f); decode16x8(q.b.raw[i][1], DT_F16, bb); }
                     const bool live = stage_row(tid, sidx, i) < rows;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = live ? f[e] - bb[e] : 0.f;

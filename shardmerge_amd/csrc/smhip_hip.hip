@@ -55,11 +55,13 @@ struct HipBackend {
     // stream s does in between, and is complete (in stream order) for everything s does after the join
     void* aux_stream() {
         if (!aux && ok()) {
-            // highest priority: its few latency-bound work-groups (the norm walker) must get onto the CUs between the row
-            // pass's work-groups, not behind the last of them
+            // (SMHIP_AUX_PRIORITY=1 / 2: highest / lowest stream priority, an experiment knob - measured on MI355X the
+            //  walker gets onto the CUs between the row pass's work-groups at any priority, tools/ab_aux.sh)
             int lo = 0, hi = 0;
             if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
-            if (hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi) != hipSuccess) { aux = nullptr; (void)hipGetLastError(); return nullptr; }
+            const char* pr = getenv("SMHIP_AUX_PRIORITY");
+            const int prio = (pr && pr[0] == '1') ? hi : ((pr && pr[0] == '2') ? lo : 0);
+            if (hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio) != hipSuccess) { aux = nullptr; (void)hipGetLastError(); return nullptr; }
             check(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming), "hipEventCreate");
             check(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming), "hipEventCreate");
         }
