@@ -403,8 +403,12 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     using AtenPartState = AtenPartStateT<MODE>;
     typename Ex::template State<AtenPartState> st;
     ex.init(st);
-    const int sig = ex.bid() % p.nsig;
-    const size_t chunk = (size_t)(ex.bid() / p.nsig);
+    // the signals of one chunk share their base rows (K deltas against ONE base): their work-groups sit on one XCD,
+    // adjacent in dispatch order (xcd_remap), so the base is fetched from HBM once and found in that L2 afterwards
+    const int lb = xcd_remap(ex.bid(), p.nsig);
+    if ((size_t)lb >= p.nchunks * (size_t)p.nsig) return;          // grid padding
+    const int sig = lb % p.nsig;
+    const size_t chunk = (size_t)(lb / p.nsig);
     const AtenSrc& s = p.src[sig];
     const size_t rows = aten_rows(s);
     const WeightRanges wr = weight_ranges(s.R, s.C, s.Cb);

@@ -1575,7 +1575,7 @@ class Pipeline {
             for (int i = 0; i < ATEN_MAX_SIGS; ++i) b.src[i] = srcs[i < nsig ? i : 0];
             int mode = aten_part_mode(srcs[0]);
             for (int i = 1; i < nsig; ++i) if (aten_part_mode(srcs[i]) != mode || srcs[i].sig.dtype != srcs[0].sig.dtype) mode = kind ? ATEN_PART_CLASS : ATEN_PART_SIGNAL;
-            const int pgrid = (int)(nchunks * nsig);
+            const int pgrid = (int)round_up(nchunks * nsig, (size_t)8 * nsig);
             const size_t plds = (LDS_SCRATCH_FLOATS + ATEN_PART_LDS_FLOATS) * 4;
             if (mode == ATEN_PART_RAW16) be.template launch<KAtenPart16>(pgrid, ATEN_THREADS, plds, b, stream);
             else if (mode == ATEN_PART_RAW32) be.template launch<KAtenPart32>(pgrid, ATEN_THREADS, plds, b, stream);
