@@ -791,6 +791,51 @@ def test_speculative_cull_selection_never_changes_a_bit(engine, k, shape):
         engine.ctx.debug_option("spec_min_bins", -1)
 
 
+def test_cull_speculation_on_alternating_layers_misses_and_changes_nothing(engine):
+    """The guess is the threshold's level-1 bin of the previous layer.  The spectra of unit-norm deltas look alike
+    whatever the deltas' scale or the tensor's size (|X| ~ 1 in every bin: the bench's and real models' hit rates are
+    ~100 %), so the layers here differ in STRUCTURE - white noise, a low-rank delta (its energy in a few bins), a
+    smooth one - which puts their cull thresholds octaves apart: every guess is wrong.  The counters the bench
+    reports (`spec_checked`, `spec_hits`) must say so and every result must be the one of the non-speculating run,
+    bit for bit; the same layer twice in a row then hits."""
+    from oracle import spectral_oracle as so
+    g = torch.Generator().manual_seed(5)
+    layers = []
+    shape = (64, 128)
+    for kind in ("white", "lowrank", "smooth"):
+        base = (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+        fts = []
+        for s_ in (0.002, 0.003):
+            d = torch.randn(shape, generator=g) * s_
+            if kind == "lowrank":
+                d = 0.02 * d + 30 * s_ * torch.randn(shape[0], 1, generator=g) * torch.randn(1, shape[1], generator=g)
+            elif kind == "smooth":
+                d = 0.01 * d + torch.cumsum(torch.cumsum(d, 0), 1) * 0.02
+            fts.append((base.float() + d).to(torch.bfloat16))
+        layers.append((fts, [base] * 2, so.ALPHAS[:2], base))
+    engine.ctx.debug_option("spec_cull", 0)
+    try:
+        off = [engine.merge_layer(*a, want_delta=True) for a in layers]
+    finally:
+        engine.ctx.debug_option("spec_cull", 1)
+    bins = {round(float(torch.log2(torch.tensor(o[1].infos[0].cull_threshold))) * 8) for o in off}
+    assert len(bins) == 3, "the three layers' cull thresholds must sit in different level-1 bins for this test"
+    engine.ctx.debug_option("spec_min_bins", 0)
+    try:
+        engine.merge_layer(*layers[0])                                   # leaves a guess behind
+        c0, h0 = engine.ctx.debug_query("spec_checked"), engine.ctx.debug_query("spec_hits")
+        order = [1, 2, 0, 1, 2, 0]
+        for i in order:
+            got = engine.merge_layer(*layers[i], want_delta=True)
+            assert torch.equal(got[0].view(torch.int16), off[i][0].view(torch.int16)) and torch.equal(got[2], off[i][2])
+        assert engine.ctx.debug_query("spec_checked") - c0 == len(order)
+        assert engine.ctx.debug_query("spec_hits") - h0 == 0
+        engine.merge_layer(*layers[0])                                   # the same layer again: a hit
+        assert engine.ctx.debug_query("spec_hits") - h0 == 1
+    finally:
+        engine.ctx.debug_option("spec_min_bins", -1)
+
+
 def _speculation_checks(engine, args, off, k):
     # a different cull fraction moves the threshold into another bin: the next guess is wrong
     engine.merge_layer(*args, cull_start_pct=0.45)

@@ -766,6 +766,10 @@ def test_speculative_cull_selection_on_device(engine, k, shape):
     emul_tier.test_speculative_cull_selection_never_changes_a_bit(engine, k, shape)
 
 
+def test_cull_speculation_on_alternating_layers_on_device(engine):
+    emul_tier.test_cull_speculation_on_alternating_layers_misses_and_changes_nothing(engine)
+
+
 @pytest.mark.parametrize("shape", [(256,), (1000,), (4096,), (1, 512), (8192,), (77,), (6144,)], ids=lambda s: "x".join(map(str, s)))
 def test_one_launch_pair_merge_of_1d_tensors_on_device(engine, shape):
     emul_tier.test_one_launch_pair_merge_of_1d_tensors(engine, shape)
