@@ -324,6 +324,7 @@ class Pipeline {
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
+    bool f1_multi = true;             // rows_first: the row passes of all raw deltas in one launch (test hook: 0 = one launch each)
     bool fuse_spec_norm = true;       // their Parseval norm comes out of the cull selection and the role-a column pass
     float noise_sigma = 1.2e-7f;      // rounding-noise model for their culled bins (k_spec_rescale)
 
@@ -684,6 +685,7 @@ class Pipeline {
         int rc = get_row_plan(g.C, p.plan, blue, bt);
         if (rc) return rc;
         p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = g.ilv;
+        p.sigs.n = 0;
         p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)g.C;
         p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
@@ -736,7 +738,11 @@ class Pipeline {
         return round_up((size_t)g.R / (rowpair ? 8 : 4), 8) * (size_t)g.pitch4;
     }
     static bool joint_rows(const Geo& g) { return g.rough > 1 && g.R % 16 == 0; }
-    int run_f1_rowpairs(const Geo& g, const SigDesc& sig, void* t1buf = nullptr, double* partials = nullptr, int* grid_out = nullptr) {
+    // multi (optional): the row passes of multi->n signals in ONE launch (F1Sigs: x, base, t1 filled in by the caller;
+    // partials are laid out here, *grid_out work-groups per signal); returns SMHIP_ERR_ARG untouched when the geometry
+    // needs a launch per slice or the chirp-z kernel - the caller then goes signal by signal
+    int run_f1_rowpairs(const Geo& g, const SigDesc& sig, void* t1buf = nullptr, double* partials = nullptr, int* grid_out = nullptr,
+                        F1Sigs* multi = nullptr) {
         F1Params p;
         bool blue; BluesteinTab bt;
         int rc = get_row_plan(g.C, p.plan, blue, bt);
@@ -745,6 +751,9 @@ class Pipeline {
         b.x = (const char*)sig.x + (size_t)g.C * dt_size(sig.dtype);
         if (sig.base) b.base = (const char*)sig.base + (size_t)g.C * dt_size(sig.dtype);
         p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = F2S_ILV;
+        p.sigs.n = 0;
+        const int nm = multi ? multi->n : 1;
+        if (multi && (blue || nm < 2 || nm > F1_MAX_SIGS)) return SMHIP_ERR_ARG;
         p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)2 * g.C;
         p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
@@ -757,7 +766,13 @@ class Pipeline {
             if ((rc = get_plan(g.R, colp))) return rc;
             p.R2 = g.R / 8; p.rowpair = 1; p.twR = colp.tw; p.ilv = F2S_ILV; p.nb = 4;      // units = row pairs
             const int gridq = (int)round_up((size_t)p.R2, 8 * p.ilv);
-            launch_fft<KF1Q>(p.plan, gridq, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
+            if (multi) {
+                if ((size_t)gridq * 2 * nm > PART_DOUBLES) return SMHIP_ERR_ARG;
+                for (int i = 0; i < nm; ++i) multi->partials[i] = p.partials + (size_t)i * 2 * gridq;
+                multi->b_off = (long long)((size_t)g.C * dt_size(sig.dtype));
+                p.sigs = *multi;
+            }
+            launch_fft<KF1Q>(p.plan, gridq * nm, 4 * p.plan.T, (LDS_SCRATCH_FLOATS + (size_t)4 * p.plan.lds_floats) * 4, p);
             if (grid_out) *grid_out = gridq;
             return SMHIP_OK;
         }
@@ -766,10 +781,19 @@ class Pipeline {
         const int nlaunch = joint ? 1 : g.batch;
         if (joint) p.R = g.R * g.rough / 2;
         const int grid = (int)round_up((size_t)(p.R + p.nb - 1) / p.nb, 8 * xgs);
+        if (multi && (nlaunch != 1 || g.rough > 1 || (size_t)grid * 2 * nm > PART_DOUBLES || !p.vec)) return SMHIP_ERR_ARG;
         if ((size_t)grid * 2 * nlaunch > PART_DOUBLES) return fail(SMHIP_ERR_SHAPE, "too many rows");
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)p.nb * p.plan.lds_floats) * 4;
         cf4* const t1base = p.t1;
         double* const pbase = p.partials;
+        if (multi) {
+            for (int i = 0; i < nm; ++i) multi->partials[i] = pbase + (size_t)i * 2 * grid;
+            multi->b_off = (long long)((size_t)g.C * dt_size(sig.dtype));
+            p.sigs = *multi;
+            launch_fft<KF1>(p.plan, grid * nm, p.nb * p.plan.T, lds, p, true);
+            if (grid_out) *grid_out = grid;
+            return SMHIP_OK;
+        }
         for (int bi = 0; bi < nlaunch; ++bi) {
             p.a = sig_at(a, (size_t)bi * g.R * g.C); p.b = sig_at(b, (size_t)bi * g.R * g.C);
             p.t1 = t1base + (size_t)bi * (g.t1_slice / 2);
@@ -1661,8 +1685,36 @@ class Pipeline {
         int rc;
         std::vector<int> grids(k);
         size_t poff = 0;
+        for (int i = 0; i < k; ++i) if ((rc = ensure(rowspec_[i], bytes))) return rc;
+        // one launch for all of them when they are alike (same dtype, aligned): the signals of a row block on one XCD
+        bool alike = f1_multi && k >= 2 && k <= F1_MAX_SIGS;
+        for (int i = 0; i < k && alike; ++i)
+            alike = stack[i].sig.dtype == stack[0].sig.dtype && stack[i].sig.prescale == 1.f && stack[i].sig.x &&
+                    (stack[i].sig.base != nullptr) == (stack[0].sig.base != nullptr) &&
+                    aligned16(stack[i].sig.x) && aligned16(stack[i].sig.base);
+        if (alike) {
+            F1Sigs ms;
+            memset(&ms, 0, sizeof ms);
+            ms.n = k;
+            for (int i = 0; i < k; ++i) { ms.x[i] = stack[i].sig.x; ms.base[i] = stack[i].sig.base; ms.t1[i] = (cf4*)rowspec_[i].p; }
+            int gq = 0;
+            rc = run_f1_rowpairs(g, stack[0].sig, rowspec_[0].p, d_part(), &gq, &ms);
+            if (rc == SMHIP_OK) {
+                for (int i = 0; i < k; ++i) {
+                    SumPartialsParams sp;
+                    sp.partials = d_part() + (size_t)i * 2 * gq; sp.nparts = gq; sp.out = mail_->norm2 + 2 * i;
+                    be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
+                }
+                be.sync(stream);
+                for (int i = 0; i < k; ++i) {
+                    stack[i].norm = std::sqrt(mail_->norm2[2 * i] + mail_->norm2[2 * i + 1]);
+                    stack[i].rows_id = i;
+                }
+                return SMHIP_OK;
+            }
+            if (rc != SMHIP_ERR_ARG) return rc;
+        }
         for (int i = 0; i < k; ++i) {
-            if ((rc = ensure(rowspec_[i], bytes))) return rc;
             if ((rc = run_f1_rowpairs(g, stack[i].sig, rowspec_[i].p, d_part() + poff, &grids[i]))) return rc;
             SumPartialsParams sp;
             sp.partials = d_part() + poff; sp.nparts = grids[i]; sp.out = mail_->norm2 + 2 * i;

@@ -306,9 +306,9 @@ def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(en
     assert tab_s["i2_rows_inv"][0] == 1 and tab_s["i1_cols_inv"][0] == 1          # only the final inverse
     # its Parseval norm comes out of the cull selection pass and the role-a column pass: no pass of its own
     assert "spec_norm" not in tab_s and tab_s["spec_norm_sum"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
-    # every raw delta's rows are transformed once, alone (the norms come with it: no delta_norms pass),
-    # and its column pass runs when the pairing has placed it
-    assert tab_s["f1_rows_fwd"][0] == k and tab_s["f2s_cols_fwd1"][0] == k
+    # every raw delta's rows are transformed once (all of them in ONE launch; the norms come with it: no delta_norms
+    # pass), and its column pass runs when the pairing has placed it
+    assert tab_s["f1_rows_fwd"][0] == 1 and tab_s["f2s_cols_fwd1"][0] == k
     assert "f2_cols_fwd" not in tab_s and "delta_norms" not in tab_s
     assert rep_s.branches == rep_m.branches
     # the fused norm equals the separate Parseval pass (same sums, other association)
@@ -789,6 +789,23 @@ def test_speculative_cull_selection_never_changes_a_bit(engine, k, shape):
         _speculation_checks(engine, args, off, k)
     finally:
         engine.ctx.debug_option("spec_min_bins", -1)
+
+
+@pytest.mark.parametrize("k,shape", [(3, (64, 128)), (4, (128, 64)), (3, (66, 40))], ids=["k3", "k4", "k3_unaligned"])
+def test_row_passes_of_all_deltas_in_one_launch_change_nothing(engine, k, shape):
+    """rows_first puts the row passes of all K raw deltas into ONE launch (the work-groups of a row block's K signals
+    on one XCD: their shared base rows come out of that L2).  Same bits as one launch per signal (test hook f1_multi)."""
+    from oracle import spectral_oracle as so
+    base, fts = _layer_inputs(shape, k, 91)
+    args = (fts, [base] * k, so.ALPHAS[:k], base)
+    one = engine.merge_layer(*args, want_delta=True)
+    engine.ctx.debug_option("f1_multi", 0)
+    try:
+        each = engine.merge_layer(*args, want_delta=True)
+    finally:
+        engine.ctx.debug_option("f1_multi", 1)
+    assert torch.equal(one[0].view(torch.int16), each[0].view(torch.int16)) and torch.equal(one[2], each[2])
+    assert one[1].delta_norms == each[1].delta_norms and one[1].branches == each[1].branches
 
 
 def test_cull_speculation_on_alternating_layers_misses_and_changes_nothing(engine):
