@@ -103,7 +103,7 @@ REF_NORM_BYTES_PER_PAIR = 0.5
 
 def moved_bytes_per_elem(k: int, norm_mode: str) -> float:
     """HBM bytes per tensor element this implementation moves for one K-way layer: 56n for
-    a raw pair (K = 2), 89n at K = 3 (every delta's rows alone, intermediates stay spectral), plus the norm
+    a raw pair (K = 2), 85n at K = 3 (every delta's rows alone, intermediates stay spectral), plus the norm
     emulation's passes in reference_cpu mode."""
     if k <= 1:
         return 8.0
@@ -111,9 +111,12 @@ def moved_bytes_per_elem(k: int, norm_mode: str) -> float:
         base = 14 + 14 + 4 + 6 + 2 + 8 + 8
     else:
         pairs = k - 1
-        base = k * 8 + k * 7 + pairs * (4 + 6 + 2) + (pairs - 1) * 4 + 16
+        # (row passes: one launch for all K deltas, the K signals of a row block on one XCD - the shared base rows are
+        #  read from HBM once: K (2 + 4) + 2 instead of 8 K; PMC: profiles/traffic_latest.json)
+        base = (k * 6 + 2) + k * 7 + pairs * (4 + 6 + 2) + (pairs - 1) * 4 + 16
     if norm_mode == "reference_cpu":
-        base += k * REF_NORM_BYTES_PER_DELTA + (k - 1) * REF_NORM_BYTES_PER_PAIR
+        # (the summary pass reads the shared base once per chunk as well: 2 K + 2 instead of 4 K)
+        base += (k * (REF_NORM_BYTES_PER_DELTA - 2.0) + 2.0) + (k - 1) * REF_NORM_BYTES_PER_PAIR
     return float(base)
 
 
