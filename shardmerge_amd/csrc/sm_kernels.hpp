@@ -215,15 +215,16 @@ struct F1Sigs {
 };
 // work-group `wg` of a launch over sg.n signals -> its signal and its block id within that signal's grid (XG: the
 // work-groups of ONE signal that share lines of T1 and must stay adjacent, see k_f1)
-SM_HD int f1_pick_signal(const F1Sigs& sg, int wg, int XG, int& sig) {
+SM_HD int pick_signal(int n, int wg, int XG, int& sig) {
     sig = 0;
-    if (sg.n <= 1) return XG > 1 ? xcd_remap(wg, XG) : wg;
-    const int G = XG * sg.n;
+    if (n <= 1) return XG > 1 ? xcd_remap(wg, XG) : wg;
+    const int G = XG * n;
     const int L = xcd_remap(wg, G);
     const int r = L % G;
     sig = r / XG;
     return (L / G) * XG + r % XG;
 }
+SM_HD int f1_pick_signal(const F1Sigs& sg, int wg, int XG, int& sig) { return pick_signal(sg.n, wg, XG, sig); }
 
 struct F1Params {
     FftPlanDev plan;       // N = C
@@ -1014,6 +1015,11 @@ struct F2SParams {
     double* im_partials;        // role a only, or null: [grid] sum w (Im a)^2 of what this work-group stored
                                 // (the Parseval norm of the pair's result when it stays spectral)
     SliceGrid sl;
+    // two = 1: BOTH inputs of a pair in one launch (one role a, one role b; no slices): the second signal's T1, role,
+    // scale and Re plane; the work-groups of the two signals alternate in blocks of XG (pick_signal) - one launch
+    // boundary less per pair merge
+    int two;
+    const cf4* t1_2; int role_a_2; float scale_2; float* re_2;
 };
 template <class P> constexpr int f2s_groups() {
     if constexpr (P::is_static) return f2_nsig_for(P::T) == 2 ? 2 * f2_bins_for(P::T, P::N) : 1; else return 1;
@@ -1036,9 +1042,13 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     constexpr int XG = G >= 8 ? 1 : 8 / G;                 // work-groups that share a 128-byte line of T1
     int bid_in_slice;
     const int slice = slice_of(ex, p.sl, bid_in_slice);
-    const cf4* const t1 = p.t1 + slice * p.sl.t1_stride;
+    int sig2 = 0;
+    const int lbid = p.two ? pick_signal(2, bid_in_slice, XG, sig2) : xcd_remap(bid_in_slice, XG);
+    const cf4* const t1 = (sig2 ? p.t1_2 : p.t1) + slice * p.sl.t1_stride;
     const size_t pl_off = slice * p.sl.plane_stride;
-    const int lbid = xcd_remap(bid_in_slice, XG);
+    const int role_a_ = sig2 ? p.role_a_2 : p.role_a;
+    const float scale_ = sig2 ? p.scale_2 : p.scale;
+    float* const re_ = sig2 ? p.re_2 : p.re;
     const int kbase = lbid * G;
     if (kbase >= p.Cb) {                      // padding work-group: its partial must still read zero
         if (p.im_partials) ex.each(st, [&](int tid, FftState&) { if (tid == 0) p.im_partials[ex.bid()] = 0.0; });
@@ -1101,12 +1111,12 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         const int k2 = kbase + g;
         s.red[0] = 0.0;
         if (k2 >= p.Cb) return;
-        const float sc = p.scale;
+        const float sc = scale_;
         size_t poff = (size_t)k2 * R;
         int kreal = k2;
         if constexpr (FOLD) { kreal = fold_bin(k2, p.slab, p.Cb_real, R, p.Rfull, poff); if (kreal < 0) return; }
         const uint32_t w = (uint32_t)bin_weight(kreal, p.C);
-        float* dre = p.re + pl_off + poff;
+        float* dre = re_ + pl_off + poff;
         float* dim = p.im + pl_off + poff;
         float imsq = 0.f;
 #pragma unroll
@@ -1115,7 +1125,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
             if (k0 + 3 < R && (R & 3) == 0) {
                 cf4 vr = {s.xr[4 * u] * sc, s.xr[4 * u + 1] * sc, s.xr[4 * u + 2] * sc, s.xr[4 * u + 3] * sc};
                 *(cf4*)(dre + k0) = vr;
-                if (p.role_a) {
+                if (role_a_) {
                     cf4 vi = {s.xi[4 * u] * sc, s.xi[4 * u + 1] * sc, s.xi[4 * u + 2] * sc, s.xi[4 * u + 3] * sc};
                     *(cf4*)(dim + k0) = vi;
                     imsq += vi.x * vi.x + vi.y * vi.y + vi.z * vi.z + vi.w * vi.w;
@@ -1125,7 +1135,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
                 for (int c = 0; c < 4; ++c) {
                     if (k0 + c < R) {
                         dre[k0 + c] = s.xr[4 * u + c] * sc;
-                        if (p.role_a) { const float vi = s.xi[4 * u + c] * sc; dim[k0 + c] = vi; imsq += vi * vi; }
+                        if (role_a_) { const float vi = s.xi[4 * u + c] * sc; dim[k0 + c] = vi; imsq += vi * vi; }
                     }
                 }
             }

@@ -324,6 +324,7 @@ class Pipeline {
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
+    bool f2s_pair = true;             // a pair of raw deltas: both single-signal column passes in one launch (test hook: 0 = two launches)
     bool f1_multi = true;             // rows_first: the row passes of all raw deltas in one launch (test hook: 0 = one launch each)
     bool fuse_spec_norm = true;       // their Parseval norm comes out of the cull selection and the role-a column pass
     float noise_sigma = 1.2e-7f;      // rounding-noise model for their culled bins (k_spec_rescale)
@@ -807,8 +808,18 @@ class Pipeline {
     }
     // im_parts (optional, role a): the kernel also leaves sum w (Im a)^2 per work-group in d_part_im();
     // *im_parts = how many
-    int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr, int* im_parts = nullptr) {
+    // second (optional): the pair's OTHER input in the same launch (its T1, role, scale); needs g.batch == 1
+    struct F2SSecond { const void* t1; bool role_a; float scale; };
+    int run_f2s(const Geo& g, bool role_a, float scale, bool hist, const void* t1buf = nullptr, int* im_parts = nullptr,
+                const F2SSecond* second = nullptr) {
         F2SParams p;
+        p.two = 0; p.t1_2 = nullptr; p.role_a_2 = 0; p.scale_2 = 0.f; p.re_2 = nullptr;
+        if (second) {
+            if (g.batch != 1 || second->role_a == role_a) return fail(SMHIP_ERR_ARG, "internal: paired column pass");
+            p.two = 1; p.t1_2 = (const cf4*)second->t1; p.role_a_2 = second->role_a ? 1 : 0; p.scale_2 = second->scale;
+            p.re_2 = plane(g, second->role_a ? P_REA : P_REB);
+        }
+        const int nsg = second ? 2 : 1;
         const int Rt = g.R / g.fold;                 // transform length (R2 on the folded path)
         int rc = get_plan(Rt, p.plan);
         if (rc) return rc;
@@ -821,9 +832,10 @@ class Pipeline {
         const bool st = is_static_plan(p.plan);
         const int G = st ? (f2_nsig_for(p.plan.T) == 2 ? 2 * f2_bins_for(p.plan.T, p.plan.N) : 1) : 1;
         const int xg = G >= 8 ? 1 : 8 / G;
-        const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg);
+        const int grid = (int)round_up((size_t)(p.Cb + G - 1) / G, 8 * xg) * nsg;
         const size_t lds = (LDS_SCRATCH_FLOATS + (size_t)G * p.plan.lds_floats + HIST1_BINS) * 4;
-        const bool want_im = im_parts && role_a && (size_t)grid * g.batch <= PART_IM_DOUBLES;
+        const bool any_a = role_a || (second && second->role_a);
+        const bool want_im = im_parts && any_a && (size_t)grid * g.batch <= PART_IM_DOUBLES;
         if (im_parts) *im_parts = want_im ? grid * g.batch : -1;
         p.im_partials = want_im ? d_part_im() : nullptr;
         if (g.fold == 4) { launch_fft<KF2SQ>(p.plan, grid, G * p.plan.T, lds, p); return SMHIP_OK; }
@@ -2045,6 +2057,14 @@ class Pipeline {
                             // planes in on its own (the level-1 histogram accumulates over both)
                             f1_ready = false;
                             int* imp = (!last_round && spectral_ok && fuse_spec_norm) ? &im_parts : nullptr;
+                            // both inputs raw with their rows done: ONE column-pass launch for the two of them
+                            if (f2s_pair && g.batch == 1 && !stack[x].spectral && !stack[y].spectral &&
+                                stack[x].rows_id >= 0 && stack[y].rows_id >= 0) {
+                                const bool xa = !swapped;
+                                F2SSecond sec{rowspec_[stack[y].rows_id].p, !xa, (float)(1.0 / (double)(float)stack[y].norm)};
+                                if ((rc = run_f2s(g, xa, (float)(1.0 / (double)(float)stack[x].norm), d.cutoff_pct > 0,
+                                                  rowspec_[stack[x].rows_id].p, imp, &sec))) return rc;
+                            } else
                             for (int side = 0; side < 2; ++side) {
                                 const Slot& in = side == 0 ? stack[x] : stack[y];
                                 const bool role_a = (side == 0) != swapped;

@@ -308,7 +308,8 @@ def test_spectral_intermediates_are_used_and_agree_with_the_materialised_path(en
     assert "spec_norm" not in tab_s and tab_s["spec_norm_sum"][0] == n_pairs - 1 and tab_s["spec_rescale"][0] == n_pairs - 1
     # every raw delta's rows are transformed once (all of them in ONE launch; the norms come with it: no delta_norms
     # pass), and its column pass runs when the pairing has placed it
-    assert tab_s["f1_rows_fwd"][0] == 1 and tab_s["f2s_cols_fwd1"][0] == k
+    # (the two column passes of a pair of raw deltas share a launch: one pair at K = 3, two at K = 4)
+    assert tab_s["f1_rows_fwd"][0] == 1 and tab_s["f2s_cols_fwd1"][0] == k - k // 2
     assert "f2_cols_fwd" not in tab_s and "delta_norms" not in tab_s
     assert rep_s.branches == rep_m.branches
     # the fused norm equals the separate Parseval pass (same sums, other association)
@@ -806,6 +807,29 @@ def test_row_passes_of_all_deltas_in_one_launch_change_nothing(engine, k, shape)
         engine.ctx.debug_option("f1_multi", 1)
     assert torch.equal(one[0].view(torch.int16), each[0].view(torch.int16)) and torch.equal(one[2], each[2])
     assert one[1].delta_norms == each[1].delta_norms and one[1].branches == each[1].branches
+
+
+@pytest.mark.parametrize("k,shape", [(3, (64, 128)), (4, (128, 64)), (3, (66, 40)), (5, (32, 64))], ids=["k3", "k4", "k3_unaligned", "k5"])
+def test_column_passes_of_a_raw_pair_in_one_launch_change_nothing(engine, k, shape):
+    """K >= 3: the two single-signal column passes of a pair of raw deltas run as ONE launch (test hook f2s_pair).  Same
+    branches and thresholds; the Parseval partial sums are reduced in another association, so the result may differ
+    in the last bits of an fp32 value - not more."""
+    from oracle import spectral_oracle as so
+    base, fts = _layer_inputs(shape, k, 93)
+    args = (fts, [base] * k, so.ALPHAS[:k], base)
+    one = engine.merge_layer(*args, want_delta=True)
+    engine.ctx.debug_option("f2s_pair", 0)
+    try:
+        two = engine.merge_layer(*args, want_delta=True)
+    finally:
+        engine.ctx.debug_option("f2s_pair", 1)
+    assert one[1].branches == two[1].branches and one[1].delta_norms == two[1].delta_norms
+    for a, b in zip(one[1].infos, two[1].infos):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert (a.cutoff_threshold, a.n_slerp) == (b.cutoff_threshold, b.n_slerp)
+    assert so.rel_err(one[2], two[2]) < 1e-6
+    assert (one[0].view(torch.int16) != two[0].view(torch.int16)).float().mean() < 1e-3
 
 
 def test_cull_speculation_on_alternating_layers_misses_and_changes_nothing(engine):
