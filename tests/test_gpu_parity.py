@@ -771,7 +771,7 @@ def test_row_passes_in_one_launch_on_device(engine, k, shape):
     emul_tier.test_row_passes_of_all_deltas_in_one_launch_change_nothing(engine, k, shape)
 
 
-@pytest.mark.parametrize("k,shape", [(3, (64, 128)), (4, (128, 64)), (3, (66, 40)), (3, (14336, 1024))], ids=["k3", "k4", "k3_unaligned", "k3_folded"])
+@pytest.mark.parametrize("k,shape", [(3, (64, 128)), (4, (128, 64)), (3, (66, 40)), (3, (4096, 1024))], ids=["k3", "k4", "k3_unaligned", "k3_4096x1024"])
 def test_column_passes_of_a_raw_pair_in_one_launch_on_device(engine, k, shape):
     emul_tier.test_column_passes_of_a_raw_pair_in_one_launch_change_nothing(engine, k, shape)
 
