@@ -519,10 +519,25 @@ template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::i
 // State must expose float xr[EREG], xi[EREG].
 // PACK = false keeps every butterfly on single floats (the inverse column pass spills
 // registers with the paired form and loses more than the shorter instruction stream wins)
-template <class P, bool PACK = true, class Ex, class StT, class NatScatter, class FinGather>
+// diagnostic builds (tools/build_variant.sh + tools/ab_kprof.sh): -DSM_DIAG_NOFFT=<mask> drops the radix passes of
+// the kernels whose bit is set (1 f1, 2 f2, 4 f2s, 8 i1, 16 i2): their memory traffic and ONE exchange remain
+#ifndef SM_DIAG_NOFFT
+#define SM_DIAG_NOFFT 0
+#endif
+template <class P, bool PACK = true, int DIAG = 0, class Ex, class StT, class NatScatter, class FinGather>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
+    if constexpr ((SM_DIAG_NOFFT & DIAG) != 0) {
+        static_for<0, 2>([&](auto comp_c) {
+            ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
+            ex.sync();
+            ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
+            ex.sync();
+        });
+        (void)N; (void)T; (void)LF;
+        return;
+    }
     if constexpr (P::is_static) {
         static_for<0, 2>([&](auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;

@@ -361,6 +361,34 @@ SM_HD void aten_acc_add2(AtenAcc& coarse, AtenAcc& fine, float x, double scale_f
         coarse.B1 += tie & (1u ^ coarse.A ^ coarse.B1) & 1u;
     }
 }
+// The same summary, EVALUATED instead of derived (round 4).  A step's increment of m = S / u depends on the running
+// sum only through its binade (u) and its parity (a tie goes to the even neighbour), and the parity after the step
+// follows from the parity before it: by induction the total increment D of a run depends on the START parity alone.
+// Two real chains of fmas over the run - one from m = 2^23 (even), one from m = 2^23 + 1 (odd) in the predicted
+// binade - therefore give D0 = A + B0 and D1 = A + B1 exactly, with the hardware's own rounding: one v_pk_fma_f32 per
+// element and candidate where the derivation above takes ~20 instructions, half of them in double precision.  A chain
+// that leaves the binade (an outlier, Inf, NaN) voids the summary, as an A >= 2^24 did.
+SM_HD vf2 aten_chain_start(int e) {
+    const uint32_t b = (uint32_t)(e + 127) << 23;
+    return mk2(u2f(b), u2f(b + 1u));
+}
+SM_HD void aten_chain_add(vf2& s, float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const vf2 yy = mk2(y, y);
+    s = __builtin_elementwise_fma(yy, yy, s);
+#else
+    s.x = std::fmaf(y, y, s.x); s.y = std::fmaf(y, y, s.y);
+#endif
+}
+SM_HD AtenSum aten_chain_sum(vf2 s, int e) {
+    const uint32_t b = (uint32_t)(e + 127) << 23;
+    const uint32_t f0 = f2u(s.x), f1 = f2u(s.y);
+    if ((f0 >> 23) != (b >> 23) || (f1 >> 23) != (b >> 23)) return aten_sum_stop();      // left the binade (or Inf / NaN)
+    const uint32_t d0 = f0 - b, d1 = f1 - (b + 1u);
+    const uint32_t a = d0 < d1 ? d0 : d1;
+    AtenSum r; r.A = (double)a; r.B0 = d0 - a; r.B1p = ((d1 - a) & 0x7fffffffu) | ((a & 1u) << 31);
+    return r;
+}
 // The chunk goes through LDS in ATEN_STAGES stages of 8 rows per thread: the loads are coalesced (8
 // consecutive threads fetch 8 consecutive rows), each thread then reads ITS 8 rows back - a thread's
 // rows must be consecutive for its summary to mean anything.
@@ -395,7 +423,7 @@ SM_HD int aten_part_mode(const AtenSrc& a) {
 template <bool RAW> struct AtenPartBuf;
 template <> struct AtenPartBuf<true> { u32x4 raw[ATEN_STAGE_ROWS][2]; };
 template <> struct AtenPartBuf<false> { float pf[ATEN_STAGE_ROWS][8]; uint32_t pw[ATEN_STAGE_ROWS]; };
-template <int MODE> struct AtenPartStateT { AtenAcc a[16]; AtenSum s[16]; AtenPartBuf<(MODE < 2)> b; double red[8]; };
+template <int MODE> struct AtenPartStateT { vf2 ch[16]; AtenSum s[16]; AtenPartBuf<(MODE < 2)> b; double red[8]; };
 template <int MODE, class Ex>
 SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     constexpr int KIND = MODE == ATEN_PART_CLASS ? 1 : 0;
@@ -465,7 +493,10 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     };
     ex.each(st, [&](int tid, AtenPartState& q) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) aten_acc_zero(q.a[i]);         // [lane][cand]: cand 0 = ep, cand 1 = ep - 1
+        for (int l = 0; l < 8; ++l) {                               // [lane][cand]: cand 0 = ep, cand 1 = ep - 1
+            const int e = ep[l] == ATEN_NO_EXP ? 0 : ep[l];
+            q.ch[2 * l] = aten_chain_start(e); q.ch[2 * l + 1] = aten_chain_start(e - 1);
+        }
         fetch(tid, q, 0);
     });
     for (int sidx = 0; sidx < ATEN_STAGES; ++sidx) {
@@ -505,9 +536,6 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
         ex.each(st, [&](int tid, AtenPartState& q) {
             // the next stage's loads are in flight while this one is summarised
             if (sidx + 1 < ATEN_STAGES) fetch(tid, q, sidx + 1);
-            double scale[8];
-#pragma unroll
-            for (int l = 0; l < 8; ++l) scale[l] = ep[l] == ATEN_NO_EXP ? 0.0 : aten_pow2(24 - ep[l]);
             const float* src = stage + (size_t)tid * ATEN_STAGE_PITCH;
 #pragma unroll
             for (int k = 0; k < ATEN_STAGE_ROWS; ++k) {
@@ -517,8 +545,10 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
 #pragma unroll
                 for (int l = 0; l < 8; ++l) {
                     const int reps = ((w2 >> l) & 1u) ? 2 : 1;
-                    if ((two >> l) & 1u) { for (int r = 0; r < reps; ++r) aten_acc_add2(q.a[2 * l], q.a[2 * l + 1], y[l], scale[l]); }
-                    else { for (int r = 0; r < reps; ++r) aten_acc_add(q.a[2 * l], y[l], scale[l] * 0.5); }
+                    for (int r = 0; r < reps; ++r) {
+                        aten_chain_add(q.ch[2 * l], y[l]);
+                        if ((two >> l) & 1u) aten_chain_add(q.ch[2 * l + 1], y[l]);
+                    }
                 }
             }
         });
@@ -526,7 +556,11 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
     }
     ex.each(st, [&](int, AtenPartState& q) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) q.s[i] = ((i & 1) && !((two >> (i / 2)) & 1u)) ? aten_sum_stop() : aten_sum_of(q.a[i]);
+        for (int i = 0; i < 16; ++i) {
+            const int e = ep[i / 2];
+            q.s[i] = ((i & 1) && !((two >> (i / 2)) & 1u)) ? aten_sum_stop()
+                   : e == ATEN_NO_EXP ? aten_sum_identity() : aten_chain_sum(q.ch[i], e - (i & 1));
+        }
     });
     for (int cand = 0; cand < 2; ++cand) {
         // (a thread's 8 summaries are 9 slots apart from the next thread's and the readers take the 8 lanes of one

@@ -443,7 +443,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
         partials_[2 * (size_t)pbid + 1] = tot[1];
     });
 
-    wg_fft<P, f1_pack<P>()>(ex, st, pl, lds,
+    wg_fft<P, f1_pack<P>(), 1>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;          // natural scatter
             const int g = tid / T, t = tid % T;
@@ -583,7 +583,7 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
     // real component, b in the pass of the imaginary one; b's raw loads are issued before a's
     // exchange and land during it), and the last gather of the imaginary component does the
     // cross-row butterfly and the stores bin by bin instead of parking 36 more values.
-    wg_fft<P, SM_F1Q_PACK>(ex, st, pl, lds,
+    wg_fft<P, SM_F1Q_PACK, 1>(ex, st, pl, lds,
         [&](int tid, F1QState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;          // natural scatter = operand load
             int tid_ = tid;
@@ -875,7 +875,7 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
-    wg_fft<P>(ex, st, pl, lds,
+    wg_fft<P, true, 2>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
@@ -1069,17 +1069,21 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
             const bool live = m < half && k2 < p.Cb;
             const int mc = m < half ? m : half - 1, kc = k2 < p.Cb ? k2 : p.Cb - 1;
             cf4 v;
+#if defined(SM_DIAG_NOMEM)
+            v = cf4{(float)q, (float)lane, 1.f, (float)kc};          // diagnostic build: no global loads
+#else
             if constexpr (FOLD) {
                 v = t1[(size_t)(kc / p.slab) * p.slab_elems + ((size_t)(mc / F2S_ILV) * p.slab + (kc % p.slab)) * F2S_ILV + mc % F2S_ILV];
             } else {
                 v = t1[((size_t)(mc / F2S_ILV) * p.pitch4 + kc) * F2S_ILV + mc % F2S_ILV];
             }
+#endif
             s.xr[2 * q] = live ? v.x : 0.f; s.xi[2 * q] = live ? v.y : 0.f; s.xr[2 * q + 1] = live ? v.z : 0.f; s.xi[2 * q + 1] = live ? v.w : 0.f;
         }
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
-    wg_fft<P>(ex, st, pl, lds,
+    wg_fft<P, true, 4>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
@@ -1124,9 +1128,15 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
             const int k0 = 4 * (t + u * T);
             if (k0 + 3 < R && (R & 3) == 0) {
                 cf4 vr = {s.xr[4 * u] * sc, s.xr[4 * u + 1] * sc, s.xr[4 * u + 2] * sc, s.xr[4 * u + 3] * sc};
+#if defined(SM_DIAG_NOMEM)
+                if (vr.x == 12345.678f)                                  // diagnostic build: no global stores
+#endif
                 *(cf4*)(dre + k0) = vr;
                 if (role_a_) {
                     cf4 vi = {s.xi[4 * u] * sc, s.xi[4 * u + 1] * sc, s.xi[4 * u + 2] * sc, s.xi[4 * u + 3] * sc};
+#if defined(SM_DIAG_NOMEM)
+                    if (vi.x == 12345.678f)
+#endif
                     *(cf4*)(dim + k0) = vi;
                     imsq += vi.x * vi.x + vi.y * vi.y + vi.z * vi.z + vi.w * vi.w;
                 }
@@ -1275,7 +1285,7 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         }
     });
 
-    wg_fft<P, false>(ex, st, pl, lds,
+    wg_fft<P, false, 8>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
@@ -1439,7 +1449,7 @@ SM_HD void k_i2(Ex& ex, const I2Params& p) {
         });
     });
 
-    wg_fft<P, f1_pack<P>()>(ex, st, pl, lds,
+    wg_fft<P, f1_pack<P>(), 16>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
