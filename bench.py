@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra timed steps in the other norm mode")
     args = ap.parse_args()
+    from shardmerge_amd.constants import tune_hip_queues
+    tune_hip_queues()                   # 8 engines + their side streams: before the first GPU call (children inherit it)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

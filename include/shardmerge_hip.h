@@ -121,11 +121,20 @@ typedef struct {
                                                the pair is blended linearly, R = F0 + t F1 (functions.py:164,196-202);
                                                unreachable at the default (the layer's own rule routes ratios < 0.1
                                                to Arithmetic-FFT first, fast_fourier.py:226) */
-    int norm_mode;                          /* 0 (default): accurate L2 norms - what the reference's device="cuda"
-                                               mode computes; 1 "reference_cpu": every spatial norm as torch's CPU
-                                               kernel returns it (8 fp32 lanes accumulated serially: biased by
-                                               -5e-3 at 67 M elements), which the reference's device="cpu" output
-                                               depends on at the 1e-2 level; ~20 ms per 8192 x 8192 norm */
+    int norm_mode;                          /* 1 "reference_cpu" - what every host entry point of this package passes by
+                                               default (shardmerge_amd/constants.py: DEFAULT_NORM_MODE): every norm the
+                                               reference takes as torch's CPU kernel returns it - acc = fma(x, x, acc)
+                                               serially in 8 fp32 lanes, biased by -5e-3 at 67 M elements - which the
+                                               reference's device="cpu" output depends on at the 1e-2 level.  EXACT (bit
+                                               for bit, csrc/sm_aten_norm.hpp) for spatial tensors: the deltas and
+                                               materialised intermediates; MODELLED for what has no spatial form here:
+                                               the gathered slerp-class vectors (sampled statistics, 1e-6 ... 4e-6 of
+                                               torch's value) and a K >= 3 intermediate kept in the spectral domain
+                                               (Gaussian model of its exact Parseval norm, ~1e-5).  Costs ~0.3 ms per
+                                               8192 x 8192 layer.  Inputs that are not 16-byte aligned are loaded element
+                                               by element; the mode never falls back to other numerics silently (an
+                                               input it cannot handle is SMHIP_ERR_ARG).
+                                               0 "exact": accurate L2 norms - the reference's device="cuda" numerics */
     int batch;                              /* 0 / 1: one [rows x cols] tensor.  > 1: a rank > 2 tensor, `batch` contiguous
                                                slices [rows x cols]: each slice is transformed on its own (the reference's
                                                fftn(dim=(-2,-1)), functions.py:58) while every norm, order statistic and
@@ -168,7 +177,7 @@ int smhip_correlate_pairs(smhip_ctx* ctx, int k, const void* const* tensors, int
 
 /* ---- torch.norm(x - base) as ATen's CPU kernel returns it for a contiguous fp32 tensor (the reference's
  *      device="cpu" norms: shard/tensor/functions.py:36,40,85, shard/merge/fast_fourier.py:152,209-210):
- *      squares rounded to fp32, accumulated serially in 8 fp32 lanes, lanes added in order, the n % 8 tail,
+ *      acc = fma(x, x, acc) - one rounding per element - serially in 8 fp32 lanes, lanes added in order, the n % 8 tail,
  *      sqrt - reproduced bit for bit by a parallel algorithm (csrc/sm_aten_norm.hpp).  x, base (may be
  *      NULL): device, `dtype`, n elements, 16-byte aligned.  norm_out: HOST float.  This is what
  *      smhip_layer_desc::norm_mode = 1 uses for every spatial norm. -------------------------------- */

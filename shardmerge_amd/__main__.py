@@ -55,6 +55,8 @@ def merge_command(config_file: Path, cache_dir: Optional[Path], verbose: bool, *
     {model, base, alpha, is_input, is_output, start_layer, end_layer}) and output_dir.
     """
     setup_logging(verbose)
+    from .constants import tune_hip_queues
+    tune_hip_queues()                   # before the first GPU call (8 engines, 8 side streams)
     try:
         config = MergeConfig.from_yaml(config_file)
         logger.info(f"Loaded configuration: {config}")

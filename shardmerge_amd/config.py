@@ -31,6 +31,8 @@ import click
 import torch
 import yaml
 
+from .constants import DEFAULT_NORM_MODE, NORM_MODES
+
 _REQUIRED = ("output_base_model", "finetune_merge", "output_dir")
 # the FFT operator's hyper-parameters and the values the reference hard-codes for them
 MERGE_OPTION_DEFAULTS = {"cutoff_pct": 0.08, "cull_start_pct": 0.20, "t_sum": 1.0, "target_norm_offset": 1e-10, "b": 0.1}
@@ -69,7 +71,7 @@ class MergeConfig:
     storage_dir: str = "storage"
     merge_options: Dict[str, float] = field(default_factory=dict)
     operator: str = "fourier"
-    norm_mode: str = "reference_cpu"
+    norm_mode: str = DEFAULT_NORM_MODE
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -130,8 +132,8 @@ class MergeConfig:
             raise click.BadParameter("finetune_merge must be a list of model URIs")
         raw["finetune_merge"] = [MergeModel(**entry) for entry in raw["finetune_merge"]]
         opts = dict(raw.get("merge_options") or {})
-        norm_mode = opts.pop("norm_mode", "reference_cpu")
-        if norm_mode not in ("exact", "reference_cpu"):
+        norm_mode = opts.pop("norm_mode", DEFAULT_NORM_MODE)
+        if norm_mode not in NORM_MODES:
             raise click.BadParameter("merge_options.norm_mode must be 'exact' or 'reference_cpu'")
         raw["norm_mode"] = norm_mode
         operator = opts.pop("operator", "fourier")

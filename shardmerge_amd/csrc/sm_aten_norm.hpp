@@ -73,6 +73,7 @@ struct AtenSrc {
     int which;                  // kind 1: 0 = the class's Re a values (v0), 1 = its Re b values (v1)
     int R, C, Cb;               // kind 1: bin multiplicities (weight_ranges)
     size_t n;                   // elements (kind 0) / plane elements (kind 1)
+    int unaligned;              // kind 0: x / base are not 16-byte aligned - rows are loaded element by element
 };
 SM_HD size_t aten_rows(const AtenSrc& s) { return s.kind == 0 ? s.n / 8 : (s.n + 7) / 8; }
 
@@ -128,7 +129,12 @@ SM_HD uint32_t aten_row_w2(const WeightRanges& w, size_t i0) {
 template <int KIND>
 SM_HD uint32_t aten_load_row(const AtenSrc& s, const WeightRanges& wr, float thr, size_t r, float* y) {
     if (KIND == 0) {
-        load_sig8(s.sig, r * 8, y);
+        if (s.unaligned) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = load_sig1(s.sig, r * 8 + e);
+        } else {
+            load_sig8(s.sig, r * 8, y);
+        }
         return 0u;
     }
     const size_t i0 = r * 8;
@@ -415,7 +421,7 @@ constexpr size_t ATEN_PART_LDS_FLOATS = (ATEN_PART_STAGE_FLOATS > ATEN_PART_TREE
 enum { ATEN_PART_RAW16 = 0, ATEN_PART_RAW32 = 1, ATEN_PART_SIGNAL = 2, ATEN_PART_CLASS = 3 };
 SM_HD int aten_part_mode(const AtenSrc& a) {
     if (a.kind != 0) return ATEN_PART_CLASS;
-    if (a.sig.prescale != 1.f || !a.sig.x) return ATEN_PART_SIGNAL;
+    if (a.sig.prescale != 1.f || !a.sig.x || a.unaligned) return ATEN_PART_SIGNAL;
     if (a.sig.dtype != DT_F32 && a.sig.base) return ATEN_PART_RAW16;
     if (a.sig.dtype == DT_F32 && !a.sig.base) return ATEN_PART_RAW32;
     return ATEN_PART_SIGNAL;

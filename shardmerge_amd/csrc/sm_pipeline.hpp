@@ -1578,13 +1578,17 @@ class Pipeline {
         if (nsig < 1 || nsig > ATEN_MAX_SIGS) return false;
         size_t max_rows = 0;
         const int kind = srcs[0].kind;
+        AtenSrc local[ATEN_MAX_SIGS];
         for (int i = 0; i < nsig; ++i) {
-            const AtenSrc& a = srcs[i];
+            local[i] = srcs[i];
+            AtenSrc& a = local[i];
             if (a.kind != kind) return false;
-            if (a.kind == 0) { if (!aligned16(a.sig.x) || !aligned16(a.sig.base)) return false; }
-            else if (!aligned16(a.reA) || !aligned16(a.reB)) return false;
+            // (an unaligned signal is loaded element by element: the mode must never fall back to other numerics silently)
+            if (a.kind == 0) a.unaligned = (!aligned16(a.sig.x) || !aligned16(a.sig.base)) ? 1 : 0;
+            else if (!aligned16(a.reA) || !aligned16(a.reB)) return false;      // planes of the workspace: always aligned
             max_rows = std::max(max_rows, aten_rows(a));
         }
+        srcs = local;
         const size_t nchunks = std::max<size_t>(1, (max_rows + ATEN_CHUNK_ROWS - 1) / ATEN_CHUNK_ROWS);
         if (nchunks * nsig > (size_t)1 << 30) return false;
         const size_t pre_bytes = round_up((size_t)nsig * nchunks * 8 * sizeof(double), 256);
@@ -1671,7 +1675,6 @@ class Pipeline {
         for (int i = 0; i < k; ++i) {
             memset(&srcs[i], 0, sizeof(AtenSrc));
             srcs[i].kind = 0; srcs[i].sig = stack[i].sig; srcs[i].n = n; srcs[i].C = -1;
-            if (!aligned16(srcs[i].sig.x) || !aligned16(srcs[i].sig.base)) return false;
         }
         aten_walk_pending_ = run_aten_norms(srcs, k, true, aux) ? aux : nullptr;
         return aten_walk_pending_ != nullptr;
@@ -1893,8 +1896,10 @@ class Pipeline {
             SigDesc sg[16];
             double nr[16];
             for (int i = 0; i < d.k; ++i) sg[i] = stack[i].sig;
-            if (run_serial_norms(sg, d.k, n, nr))
-                for (int i = 0; i < d.k; ++i) stack[i].norm = nr[i];
+            // (never a silent fall-back to accurate norms: the caller asked for the reference's device="cpu" numerics)
+            if (!run_serial_norms(sg, d.k, n, nr))
+                return fail(SMHIP_ERR_ARG, "norm_mode = reference_cpu: the torch.norm emulation does not apply to these inputs");
+            for (int i = 0; i < d.k; ++i) stack[i].norm = nr[i];
         }
         double mean = 0;
         for (int i = 0; i < d.k; ++i) {
@@ -2158,7 +2163,12 @@ class Pipeline {
                     if (grid < 0) run_combine(ms, none, 0.f, 0.f, n, nullptr, nullptr, true, &grid);
                     double nm, dummy;
                     read_norms(grid, nm, dummy);
-                    if (ref_norms) { double nr; if (run_serial_norms(&ms, 1, n, &nr)) nm = nr; }
+                    if (ref_norms) {
+                        double nr;
+                        if (!run_serial_norms(&ms, 1, n, &nr))
+                            return fail(SMHIP_ERR_ARG, "norm_mode = reference_cpu: the torch.norm emulation does not apply to an intermediate");
+                        nm = nr;
+                    }
                     out_norm = nm;
                     Slot s;
                     s.sig = ms; s.weight = (a_w + b_w) / 2.0; s.norm = out_norm;

@@ -39,7 +39,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .config import MergeConfig
-from .constants import INPUT_LAYER, OUTPUT_LAYER
+from .constants import DEFAULT_NORM_MODE, INPUT_LAYER, OUTPUT_LAYER
 from .index import LocalModelIndex
 from .merge.fast_fourier import FourierMerge
 from .writer import ShardLayer
@@ -198,7 +198,7 @@ def config_stamp(config: MergeConfig) -> str:
     doc = {"output_base_model": config.output_base_model, "output_dtype": config.output_dtype,
            "finetune_merge": [asdict(m) for m in config.finetune_merge],
            "merge_options": dict(sorted((config.merge_options or {}).items())),
-           "operator": getattr(config, "operator", "fourier"), "norm_mode": getattr(config, "norm_mode", "exact")}
+           "operator": getattr(config, "operator", "fourier"), "norm_mode": getattr(config, "norm_mode", None) or DEFAULT_NORM_MODE}
     return hashlib.sha256(json.dumps(doc, sort_keys=True, default=str).encode()).hexdigest()[:16]
 
 

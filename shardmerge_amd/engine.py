@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
+from .constants import DEFAULT_NORM_MODE, NORM_MODES
 from ._lib import BlendInfo, Context, LayerDesc, LayerReport, SmhipError, SmhipLibrary
 
 logger = logging.getLogger(__name__)
@@ -248,7 +249,7 @@ class Engine:
     def merge_layer(self, finetunes: Sequence[torch.Tensor], bases: Sequence[torch.Tensor], alphas: Sequence[float],
                     base_out: torch.Tensor, target_norm_offset: float = 1e-10, cull_start_pct: float = 0.20,
                     cutoff_pct: float = 0.08, t_sum: float = 1.0, want_delta: bool = False,
-                    layer_name: str = "layer", b: float = 0.1, norm_mode: str = "exact"):
+                    layer_name: str = "layer", b: float = 0.1, norm_mode: Optional[str] = None):
         k = len(finetunes)
         if k < 1 or k > _lib.MAX_MODELS:
             raise ValueError(f"{k} models to merge: supported range is 1..{_lib.MAX_MODELS}")
@@ -290,7 +291,9 @@ class Engine:
         desc.cutoff_pct = float(cutoff_pct)
         desc.t_sum = float(t_sum)
         desc.b = float(b)
-        if norm_mode not in ("exact", "reference_cpu"):
+        if norm_mode is None:
+            norm_mode = DEFAULT_NORM_MODE            # one default everywhere (constants.py)
+        if norm_mode not in NORM_MODES:
             raise ValueError(f"norm_mode {norm_mode!r}: 'exact' or 'reference_cpu'")
         desc.norm_mode = 1 if norm_mode == "reference_cpu" else 0
         desc.batch = nb

@@ -15,7 +15,7 @@ from typing import List, Optional
 import torch
 
 from ..config import MergeConfig, MergeModel
-from ..constants import INPUT_LAYER, OUTPUT_LAYER
+from ..constants import DEFAULT_NORM_MODE, INPUT_LAYER, OUTPUT_LAYER
 from ..index import LocalModelIndex
 from ..writer import ShardLayer
 from .base import MergeTensorsBase
@@ -41,7 +41,7 @@ class FourierMerge(MergeTensorsBase):
         self.cutoff_pct = 0.08          # fast_fourier.py:239
         self.t_sum = 1.0                # fast_fourier.py:238
         self.b = 0.1                    # functions.py:164 (merge_tensors_fft2_slerp's default, never overridden there)
-        self.norm_mode = getattr(config, "norm_mode", "exact")
+        self.norm_mode = getattr(config, "norm_mode", None) or DEFAULT_NORM_MODE
         # optional YAML overrides (config.merge_options); absent keys keep the reference's values
         for key, value in (getattr(config, "merge_options", None) or {}).items():
             setattr(self, key, float(value))

@@ -261,14 +261,15 @@ def masked_spectral_check(delta, tr, tol_outside=OUTSIDE_CULLED_TOL):
     return outside, inside, n_flips
 
 
-def check_layer(engine, golden, case):
+def check_layer(engine, golden, case, norm_mode=None):
     tensors, use, cfg, lname = models_in_window(case)
     fts = [tensors[m["model"]] for m in use]
     bases = [tensors[m["base"]] for m in use]
     alphas = [m["alpha"] for m in use]
     tr = so.LayerTrace()
     so.merge_layer(fts, bases, alphas, tensors[cfg["output_base_model"]], names=[m["model"] for m in use], trace=tr)
-    out, rep, delta = engine.merge_layer(fts, bases, alphas, tensors[cfg["output_base_model"]], want_delta=True, layer_name=lname)
+    out, rep, delta = engine.merge_layer(fts, bases, alphas, tensors[cfg["output_base_model"]], want_delta=True, layer_name=lname,
+                                         norm_mode=norm_mode)       # None: the product's default (constants.DEFAULT_NORM_MODE)
     out, delta = out.cpu(), delta.cpu()
     ref = golden.get("g7_layer.safetensors", case["id"])
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape            # reference test_fast_fourier.py:320

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
+    from shardmerge_amd.constants import tune_hip_queues
+    tune_hip_queues()
     root = Path(args.root)
     if root.exists():
         shutil.rmtree(root)
