@@ -198,6 +198,8 @@ int smhip_reference_cpu_norm(smhip_ctx* ctx, const void* x, const void* base, in
  *      "sel_wgs_per_cu" the resident work-groups per CU its grid is sized for (0 = default 5), and
  *      "sel_flush_always" flushes its staged candidates after every round (the
  *      mid-stream flush that only very large tensors reach otherwise);
+ *      "noise_seed" = s offsets the seed of the rounding-noise model that a spectral intermediate's culled bins
+ *      receive (another realisation of the same statistics; default 0);
  *      "spectral_intermediates" = 0 makes a K >= 3 tournament materialise every intermediate
  *      (inverse transform to fp32, forward again) as round 1 of this library did, instead of
  *      keeping it in the spectral domain (default 1). ----------------------------------- */

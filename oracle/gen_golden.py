@@ -37,7 +37,7 @@ import shard.tensor.functions as ref_fn  # noqa: E402  (the reference)
 from shard.config import MergeConfig, MergeModel  # noqa: E402
 from shard.download import DownloadManager  # noqa: E402
 from shard.index import HFMultiModelIndex  # noqa: E402
-from shard.merge.fast_fourier import FourierMerge  # noqa: E402
+from shard.merge.fast_fourier import FourierMerge, TensorDiskCache  # noqa: E402
 from shard.writer import ShardLayer  # noqa: E402
 
 OUT = REPO / "tests" / "golden"
@@ -178,6 +178,46 @@ def gen_layers(manifest):
     manifest["layer_self_floor"] = floors
 
 
+def run_ref_layer_with_delta(case, tmp):
+    """run_ref_layer plus the fp32 merged delta: the last tensor the reference's TensorDiskCache hands back
+    (fast_fourier.py:256-257, `result_tensor`) before the add-back and the bf16 cast."""
+    seen = []
+    orig_get = TensorDiskCache.get
+
+    def spy(self, *a, **k):
+        t = orig_get(self, *a, **k)
+        if t is not None:
+            seen.append(t)
+        return t
+    with patch.object(TensorDiskCache, "get", spy):
+        out = run_ref_layer(case, tmp)
+    return out, seen[-1].float().clone()
+
+
+def gen_floor(manifest):
+    """G11: K = 3 / K = 4 layers at 1024 x 1024: the reference's output and merged delta, as it is and with its FFTs
+    evaluated in float64 (fp64_fft) - the distance between the two is the reference's own reproducibility floor."""
+    store, meta = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for case in gi.FLOOR_CASES:
+            out, delta = run_ref_layer_with_delta(case, tmp)
+            with fp64_fft():
+                out64, delta64 = run_ref_layer_with_delta(case, tmp)
+            cid = case["id"]
+            store[cid + "/out"] = out.contiguous().clone()
+            store[cid + "/out_fp64"] = out64.contiguous().clone()
+            store[cid + "/delta_f16"] = (delta * gi.FLOOR_DELTA_SCALE).to(torch.float16).contiguous()
+            store[cid + "/delta_fp64_f16"] = (delta64 * gi.FLOOR_DELTA_SCALE).to(torch.float16).contiguous()
+            tensors, _, _, _ = gi.layer_inputs(case)
+            manifest["inputs"][cid] = sum((gi.checksum(v) for v in tensors.values()), [])
+            rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+            meta[cid] = {"out_floor": rel(out64.float(), out.float()), "delta_floor": rel(delta64, delta),
+                         "delta_norm": float(delta.double().norm())}
+            print(cid, meta[cid])
+    save_file(store, str(OUT / "g11_floor.safetensors"))
+    manifest["floor_meta"] = meta
+
+
 def gen_cli(manifest):
     """G8: the reference CLI end to end on a tiny local model."""
     from click.testing import CliRunner
@@ -256,6 +296,12 @@ def main():
         with open(OUT / "manifest.json", "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
+    if "--only-floor" in sys.argv:               # add G11 without touching the other fixtures
+        manifest = json.load(open(OUT / "manifest.json"))
+        gen_floor(manifest)
+        with open(OUT / "manifest.json", "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if "--only-addition" in sys.argv:            # add G9 without touching the other fixtures
         manifest = json.load(open(OUT / "manifest.json"))
         gen_addition(manifest)
@@ -272,6 +318,7 @@ def main():
     gen_cli(manifest)
     gen_addition(manifest)
     gen_corr(manifest)
+    gen_floor(manifest)
     with open(OUT / "manifest.json", "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     total = sum(p.stat().st_size for p in OUT.glob("*.safetensors"))

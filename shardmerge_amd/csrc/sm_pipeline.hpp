@@ -323,6 +323,7 @@ class Pipeline {
     int debug_force_split = 0;        // test hook: split a column length into this many row blocks even if it has a plan
     int sel_wgs_per_cu = 5;           // level-2 selection pass: work-groups per CU its grid is sized for
     bool safe_select = false;         // full-pass selection (no candidate lists): the retry mode after an overflow
+    uint32_t noise_seed_base = 0;     // test hook "noise_seed": another realisation of the noise model (seed-sensitivity test)
     bool spectral_inter = true;       // K >= 3: intermediates of the tournament stay in the spectral domain
     bool f2s_pair = true;             // a pair of raw deltas: both single-signal column passes in one launch (test hook: 0 = two launches)
     size_t f2s_pair_max_bins = (size_t)64 << 20;   // ... for spectra up to this many bins
@@ -1932,7 +1933,7 @@ class Pipeline {
             for (int i = 0; i < 4; ++i) working = working || pidx_[i] == (int)q;
             pool_busy_[q] = working ? 1 : 0;
         }
-        noise_seed_ = 0;                         // the noise model is a function of (layer step, bin): runs repeat bit for bit
+        noise_seed_ = noise_seed_base;           // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
         int round_idx = 0;                       // tournament round: the cull fraction (and its speculation slot) goes with it
         int deferred_step = -1;

@@ -246,7 +246,7 @@ class _InPlaceShardWriter:
                 plan = self.plans[shard]
                 if shard not in self.fds:
                     self.fds[shard] = os.open(self.out_dir / f".tmp-{shard}", os.O_WRONLY)
-                view = memoryview(host.view(torch.uint8).reshape(-1).numpy()).cast("B")
+                view = memoryview(host.reshape(-1).view(torch.uint8).numpy()).cast("B")      # (reshape first: a 0-dim tensor has no byte view)
                 pos, done = plan["data_start"] + plan["offsets"][name][0], 0
                 while done < len(view):
                     done += os.pwrite(self.fds[shard], view[done:done + (1 << 30)], pos + done)
@@ -256,13 +256,22 @@ class _InPlaceShardWriter:
             finally:
                 self.jobs.task_done()
 
-    def close(self):
-        self.jobs.put(None)
-        self.thread.join()
+    def close(self, abort: bool = False):
+        """join the writer thread and close the files; abort=True (another error is already on its way up): no fsync,
+        and a write error found here does not mask the first one"""
+        if self.thread.is_alive():
+            self.jobs.put(None)
+            self.thread.join()
         for fd in self.fds.values():
-            os.fsync(fd)
-            os.close(fd)
-        if self.error is not None:
+            try:
+                if not abort:
+                    os.fsync(fd)
+                os.close(fd)
+            except OSError:
+                if not abort:
+                    raise
+        self.fds.clear()
+        if self.error is not None and not abort:
             raise self.error
 
 
@@ -508,10 +517,22 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
                     work = dist.broadcast(flat, src=root_of[s], async_op=True)      # THE collective: RCCL over xGMI
             inflight[s] = (flat, work, block, offs)
 
+    # A rank that fails says so in the process group's store before it goes down: the others look there at every
+    # shard and in front of the barrier and stop with an error of their own instead of waiting for ever.  (A rank
+    # blocked INSIDE a collective whose root has died is beyond this: run with a process-group timeout.)  The output
+    # directory must be a node-local or coherent POSIX file system: several ranks pwrite() into one shard file.
+    fail_key = f"shardmerge/{run_id}/failed"
+
+    def peers_alive():
+        if store is not None and world > 1 and store.add(fail_key, 0) > 0:
+            raise RuntimeError(f"rank {me}: another rank of this merge has failed (see its log); stopping")
+
     t_wait = t_merge = 0.0
     t_start = time.time()
+    ok = False
     try:
         for si, s in enumerate(todo):
+            peers_alive()
             issue_broadcasts(si + window)
             flat, work, block, offs = inflight.pop(s)
             if any((s, n) in mine for n in names_of[s]):
@@ -546,23 +567,36 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             elif work is not None:
                 work.wait()                               # (the buffer must outlive the collective)
             del flat
+        writer.jobs.join()
+        publish_finished()
+        writer.close()
+        ok = True
     finally:
         reader.close()
         if loader is not None:
             loader.close()
             merger._loader = None
-    writer.jobs.join()
-    publish_finished()
-    writer.close()
+        if not ok:
+            # this rank is going down: tell the others, then release the writer thread and its files (the .tmp-* shards
+            # stay behind for the next run, which recreates them)
+            try:
+                if store is not None and world > 1:
+                    store.add(fail_key, 1)
+            except Exception:
+                pass
+            writer.close(abort=True)
     busy = time.time() - t_start
     logger.info(f"rank {me}: merged {len(mine)} tensors in {busy:.2f} s; waited {t_wait:.2f} s for base shards "
                 f"(idle {100.0 * t_wait / max(busy, 1e-9):.1f} %)")
 
+    peers_alive()
     if dist is not None:
         dist.barrier()
     if me == 0:
         missing = [s for s in todo if not (out_dir / s).exists()]
         if missing:
+            if store is not None and world > 1:
+                store.add(fail_key, 1)
             raise RuntimeError(f"Incomplete model output: shards {missing} were not completed")
         with open(out_dir / "model.safetensors.index.json", "w") as fh:
             json.dump(index.model_indexes[base_uri], fh, indent=2)

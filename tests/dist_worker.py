@@ -24,6 +24,20 @@ def main():
     real = os.environ.get("SHARDMERGE_TEST_REAL_ENGINE") == "1"      # the GPU tier: real engines, several ranks on one card (gloo)
     if not real:
         distributed.ENGINE_FACTORY = emul_engine
+        if os.environ.get("SHARDMERGE_TEST_FAULT_RANK") == os.environ.get("RANK"):
+            # fault injection (test_a_failing_rank_stops_the_others): this rank's second merge raises
+            def faulty():
+                eng = emul_engine()
+                real_merge, calls = eng.merge_layer, [0]
+
+                def merge_layer(*a, **k):
+                    calls[0] += 1
+                    if calls[0] >= 2:
+                        raise RuntimeError("injected fault")
+                    return real_merge(*a, **k)
+                eng.merge_layer = merge_layer
+                return eng
+            distributed.ENGINE_FACTORY = faulty
     idx = LocalModelIndex(cfg.storage_path)
     asyncio.run(distributed.run_partitioned_merge(cfg, idx, "cuda" if real else "cpu"))
     import torch.distributed as dist

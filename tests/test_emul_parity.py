@@ -959,3 +959,18 @@ def test_1d_policies_through_the_one_launch_kernel(engine):
     big[5] = float("inf")
     with pytest.raises(ValueError):
         engine.merge_layer(fts, [base] * 2, so.ALPHAS[:2], big)
+
+
+# ---- K >= 3 against reference-held floor data (tests/golden/g11_floor.safetensors, oracle/gen_golden.py --only-floor) --
+@pytest.mark.parametrize("case", gi.FLOOR_CASES, ids=lambda c: c["id"])
+def test_k3_k4_within_the_reference_own_floor(engine, golden, case):
+    """1024 x 1024, K = 3 and K = 4, the product's default mode: d(HIP, reference) <= 1.25 d(reference with fp64 FFTs,
+    reference) on the bf16 output and on the merged delta (reference fast_fourier.py:171-254,
+    functions.py:124-148)."""
+    rec = pc.check_floor(engine, golden, case)
+    print(rec)
+
+
+def test_noise_model_seed_does_not_matter_beyond_the_floor(engine, golden):
+    d01, d02, floor = pc.check_noise_seed_sensitivity(engine, golden, gi.FLOOR_CASES[0])
+    print(f"two other seeds move the K = 3 output by {d01:.2e} / {d02:.2e}; the reference's own floor is {floor:.2e}")

@@ -161,7 +161,7 @@ def test_layer_k3_k4_vs_oracle(engine, k):
     print(f"K={k}: outside the culled bins {outside:.2e}, inside {inside:.2e}, final-cull flips {flips}")
     # the irreproducible part (the reference's own chaos floor on the bf16 output: 1.6e-3 at
     # K = 3, 3.1e-2 at K = 4, every size) bounds the total
-    assert so.rel_err(out.cpu().float(), ref.float()) < (5e-3 if k == 3 else 8e-2)
+    assert so.rel_err(out.cpu().float(), ref.float()) < (2e-3 if k == 3 else 4e-2)
 
 
 # ---- full-size properties (8192 x 8192: BASELINE's shape) ---------------------------
@@ -507,7 +507,7 @@ def _fullsize_as_is(engine, rows, cols, k, seed, tag, masked=True):
         for drop in (64, 256):
             rec[f"delta_beyond_{drop}_tie_bins"] = pc.spectral_residual(delta, tr.merged_delta, drop=drop)[1]
     elif masked:
-        outside, inside, flips = pc.masked_spectral_check(delta, tr)
+        outside, inside, flips = pc.masked_spectral_check(delta, tr, device="cuda" if masked == "device" else "cpu")
         rec.update({"delta_outside_culled_bins": outside, "delta_inside_culled_bins": inside, "final_cull_flips": flips})
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
@@ -541,7 +541,7 @@ def test_8192sq_fullsize_k3_as_is(engine):
     round 1 culled; the total is held to 3x that floor."""
     rec = _fullsize_as_is(engine, 8192, 8192, 3, 5151, "parity_fullsize_8192sq_k3")
     assert rec["branches"].count("slerp") == 2
-    assert rec["out_rel_err"] < 5e-3, rec
+    assert rec["out_rel_err"] < 2e-3, rec          # (the reference-held floor at 1024^2: 1.47e-3, g11_floor)
     assert rec["delta_outside_culled_bins"] < 1e-3, rec
 
 
@@ -550,15 +550,57 @@ def test_llama3_8b_mlp_shape_fullsize_k4_as_is(engine):
     intermediates.  The reference's own K = 4 floor is 3.1e-2 on the bf16 output."""
     rec = _fullsize_as_is(engine, 14336, 4096, 4, 6161, "parity_fullsize_8b_mlp_k4")
     assert rec["branches"].count("slerp") == 3
-    assert rec["out_rel_err"] < 8e-2, rec
+    assert rec["out_rel_err"] < 4e-2, rec          # (the reference-held K = 4 floor: 3.06e-2, g11_floor)
     assert rec["delta_outside_culled_bins"] < pc.OUTSIDE_CULLED_TOL, rec     # (measured 1.7e-3: two rounds of culled bins feed the last merge)
 
 
 def test_llama3_70b_mlp_shape_fullsize_k3_as_is(engine):
     """[28672 x 8192], K = 3 - the metric's configuration on its dominant tensor: steps checked, totals recorded."""
-    rec = _fullsize_as_is(engine, 28672, 8192, 3, 7171, "parity_fullsize_70b_mlp_k3", masked=False)
+    rec = _fullsize_as_is(engine, 28672, 8192, 3, 7171, "parity_fullsize_70b_mlp_k3", masked="device")
     assert rec["branches"].count("slerp") == 2
-    assert rec["out_rel_err"] < 5e-3, rec
+    assert rec["out_rel_err"] < 2e-3, rec
+    assert rec["delta_outside_culled_bins"] < 1e-3, rec
+
+
+# ---- K >= 3 against reference-held floor data, on the device ---------------------------------------
+@pytest.mark.parametrize("norm_mode", ["reference_cpu", "exact"])
+@pytest.mark.parametrize("case", gi.FLOOR_CASES, ids=lambda c: c["id"])
+def test_k3_k4_within_the_reference_own_floor_on_device(engine, golden, case, norm_mode):
+    rec = pc.check_floor(engine, golden, case, norm_mode=norm_mode)
+    print(rec)
+
+
+def test_noise_model_seed_does_not_matter_beyond_the_floor_on_device(engine, golden):
+    emul_tier.test_noise_model_seed_does_not_matter_beyond_the_floor(engine, golden)
+
+
+def _k3_bar(n):
+    """the K = 3 bar on the bf16 output: 2e-3 (the reference-held floor is 1.47e-3, tests/golden/manifest.json) once the
+    threshold-tie floor 8 / sqrt(n) is below it"""
+    return max(2e-3, 8.0 / math.sqrt(n))
+
+
+def test_llama3_70b_mlp_down_shape_fullsize_k3_as_is(engine):
+    """[8192 x 28672], K = 3: the 28672-point ROW plans (KF1<28672>, KI2<28672>) in the metric's configuration."""
+    rec = _fullsize_as_is(engine, 8192, 28672, 3, 7272, "parity_fullsize_70b_mlp_down_k3", masked="device")
+    assert rec["branches"].count("slerp") == 2
+    assert rec["out_rel_err"] < 2e-3, rec
+    assert rec["delta_outside_culled_bins"] < 1e-3, rec
+
+
+def test_llama3_70b_kv_proj_shape_k3_as_is(engine):
+    """[1024 x 8192] (k_proj / v_proj of Llama-3-70B), K = 3."""
+    rec = _fullsize_as_is(engine, 1024, 8192, 3, 7373, "parity_fullsize_70b_kv_k3")
+    assert rec["branches"].count("slerp") == 2
+    assert rec["out_rel_err"] < _k3_bar(1024 * 8192), rec
+    assert rec["delta_outside_culled_bins"] < 1e-3, rec
+
+
+def test_llama3_70b_norm_weight_1d_k3_as_is(engine):
+    """[8192] (input_layernorm / post_attention_layernorm weights), K = 3 through the one-launch 1-D pair merge."""
+    rec = _fullsize_as_is(engine, 0, 8192, 3, 7474, "parity_fullsize_70b_norm1d_k3", masked=False)
+    assert rec["branches"].count("slerp") == 2
+    assert rec["out_rel_err"] < _k3_bar(8192), rec
 
 
 # ---- N3 / N4 on the device ------------------------------------------------------------------------
