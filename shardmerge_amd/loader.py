@@ -16,12 +16,15 @@ import json
 import logging
 import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from . import iostats
 
 logger = logging.getLogger(__name__)
 
@@ -106,18 +109,22 @@ class PrefetchLoader:
             torch.cuda.set_device(self.device)
         f = self.files[self.index.shard_path(uri, name)]
         shape, dtype, nbytes = f.meta(name)
-        host = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=self.on_gpu)[:nbytes]
+        with iostats.timed("pinned_alloc"):
+            host = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=self.on_gpu)[:nbytes]
         if nbytes:
-            f.read_into(name, host)
+            with iostats.timed("read", nbytes):          # (summed over the read threads)
+                f.read_into(name, host)
         self.bytes_read += nbytes
         cpu = host.view(dtype).reshape(shape) if nbytes else torch.empty(shape, dtype=dtype)
         if not self.on_gpu:
             return cpu, None, None
         with torch.cuda.stream(self.copy_stream):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(self.copy_stream)
             dev = cpu.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(self.copy_stream)
-        return dev, ev, host          # host stays referenced until the copy has been waited for
+        return dev, ev, (host, ev0, nbytes)          # host stays referenced until the copy has been waited for
 
     def _run(self):
         try:
@@ -159,6 +166,7 @@ class PrefetchLoader:
         if li >= len(self.schedule) or (uri, name) not in self.schedule[li]:
             return None
         key = (li, uri, name)
+        t_wait = time.perf_counter()
         with self.cv:
             while key not in self.ready and self.error is None:
                 self.cv.wait()
@@ -171,12 +179,15 @@ class PrefetchLoader:
                 self.cv.notify_all()
         if ev is not None:
             ev.synchronize()                  # copy done: the pinned buffer may go
+            _, ev0, nbytes = host
+            iostats.add("h2d", ev0.elapsed_time(ev) * 1e-3, nbytes)      # on the copy stream (overlaps the merge)
             del host
             # `dev` was allocated on the copy stream's pool but is consumed (merge kernels, the
             # writer's asynchronous device-to-host copy of passthrough tensors) on the caller's
             # stream: without this the block returns to the copy stream's pool the moment the
             # caller drops it and the next prefetch may overwrite it under a copy still in flight
             dev.record_stream(torch.cuda.current_stream(self.device))
+        iostats.add("take_wait", time.perf_counter() - t_wait)           # the merge stalled on its inputs
         return dev
 
     def close(self):

@@ -14,6 +14,7 @@ from typing import List, Optional
 
 import torch
 
+from .. import iostats
 from ..config import MergeConfig, MergeModel
 from ..constants import DEFAULT_NORM_MODE, INPUT_LAYER, OUTPUT_LAYER
 from ..index import LocalModelIndex
@@ -154,10 +155,11 @@ class FourierMerge(MergeTensorsBase):
         fts = [await fetch(m.model) for m in models]
         bases = [await fetch(m.base) for m in models]
         base_out = await fetch(self.config.output_base_model)
-        out, report = eng.merge_layer(
-            fts, bases, [m.alpha for m in models], base_out,
-            target_norm_offset=self.target_norm_offset, cull_start_pct=self.cull_start_pct,
-            cutoff_pct=self.cutoff_pct, t_sum=self.t_sum, b=self.b, norm_mode=self.norm_mode, layer_name=name)
+        with iostats.timed("merge", 2 * base_out.numel()):       # (the library syncs for its norms: ~ the layer's device time)
+            out, report = eng.merge_layer(
+                fts, bases, [m.alpha for m in models], base_out,
+                target_norm_offset=self.target_norm_offset, cull_start_pct=self.cull_start_pct,
+                cutoff_pct=self.cutoff_pct, t_sum=self.t_sum, b=self.b, norm_mode=self.norm_mode, layer_name=name)
         self.last_report = report
         logger.info(f"Merged {name}: {len(models)} model(s), branches {report.branches}, target norm {report.target_norm:.6g}")
         return out

@@ -22,6 +22,8 @@ from pathlib import Path
 from typing import Dict, Generator, List, Set, Tuple
 
 import torch
+
+from . import iostats
 from safetensors import safe_open
 from safetensors.torch import save_file
 
@@ -141,11 +143,13 @@ class ModelWriter:
                     merged[k] = fh.get_tensor(k)
         for k, (t, ev) in fresh.items():
             if ev is not None:
-                ev.synchronize()
+                with iostats.timed("d2h_wait", t.numel() * t.element_size()):
+                    ev.synchronize()
             merged[k] = t
         ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
         tmp = path.with_name(f".tmp-{path.name}")
-        save_file(ordered, str(tmp), metadata={"format": "pt"})
+        with iostats.timed("save", sum(t.numel() * t.element_size() for t in ordered.values())):
+            save_file(ordered, str(tmp), metadata={"format": "pt"})
         os.replace(tmp, path)                  # resume must never see a half-written shard
         with self._lock:
             for k in fresh:

@@ -358,11 +358,16 @@ def test_misaligned_device_inputs_take_the_elementwise_path(engine):
     assert base.data_ptr() % 16 != 0 and base.is_contiguous()
     ft0 = (base.float() + torch.randn(32, 1024, generator=g).cuda() * 0.002).to(torch.bfloat16)
     ft1 = (base.float() + torch.randn(32, 1024, generator=g).cuda() * 0.003).to(torch.bfloat16)
-    out_u, rep_u = engine.merge_layer([ft0, ft1], [base, base], [0.3, 0.5], base)
-    out_a, rep_a = engine.merge_layer([ft0, ft1], [base.clone(), base.clone()], [0.3, 0.5], base.clone())
-    assert rep_u.branches == rep_a.branches == ["slerp"]
-    assert (out_u != out_a).float().mean().item() < 1e-3     # two plans (static / run-time): ulps apart
-    assert so.rel_err(out_u.float().cpu(), out_a.float().cpu()) < 1e-5
+    for mode, bar in (("exact", 1e-5), ("reference_cpu", 5e-5)):
+        out_u, rep_u = engine.merge_layer([ft0, ft1], [base, base], [0.3, 0.5], base, norm_mode=mode)
+        out_a, rep_a = engine.merge_layer([ft0, ft1], [base.clone(), base.clone()], [0.3, 0.5], base.clone(), norm_mode=mode)
+        assert rep_u.branches == rep_a.branches == ["slerp"]
+        # the torch.norm emulation takes unaligned inputs element by element: the same bits, never other numerics
+        assert rep_u.delta_norms == rep_a.delta_norms
+        if mode == "reference_cpu":
+            assert rep_u.delta_norms == [float((f.float().cpu() - base.float().cpu()).norm()) for f in (ft0, ft1)]
+        assert (out_u != out_a).float().mean().item() < 1e-3     # two plans (static / run-time): ulps apart
+        assert so.rel_err(out_u.float().cpu(), out_a.float().cpu()) < bar, mode
 
 
 # ---- the BASELINE configs' REAL tensor shapes against the oracle (slow: the oracle's two sorts) ----

@@ -49,6 +49,37 @@ __global__ void __launch_bounds__(G * 256) colread(const float4* __restrict__ t1
     }
 }
 
+// colread with the plane stores of a LAST radix pass written directly (no final exchange): thread t holds outputs
+// t + 256 u, u < 32, and stores them as dwords - a wave-instruction writes 256 contiguous bytes (two lines) where the
+// exchanged form writes 1 KB (eight lines) with dwordx4
+template <int G>
+__global__ void __launch_bounds__(G * 256) colread_dwstore(const float4* __restrict__ t1, float* __restrict__ re, float* __restrict__ im, int M, int P, int ncols) {
+    constexpr int XG = (G >= 8) ? 1 : 8 / G;
+    const int lbid = xcd_remap(blockIdx.x, XG);
+    const int kbase = lbid * G;
+    if (kbase >= ncols) return;
+    const int b = threadIdx.x % G, lane = threadIdx.x / G;
+    float4 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = t1[(size_t)(lane + q * 256) * P + kbase + b];
+    const int g = threadIdx.x / 256, t = threadIdx.x % 256;
+    float* dre = re + (size_t)(kbase + g) * (2 * M);
+    float* dim = im + (size_t)(kbase + g) * (2 * M);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        dre[t + 256 * (2 * u)] = v[u].x; dre[t + 256 * (2 * u + 1)] = v[u].z;
+        dim[t + 256 * (2 * u)] = v[u].y; dim[t + 256 * (2 * u + 1)] = v[u].w;
+    }
+}
+template <int G>
+void run_colread_dw(const float4* t1, float* re, float* im, int M, int P, int ncols) {
+    constexpr int XG = (G >= 8) ? 1 : 8 / G;
+    const int nwg = ncols / G;
+    const int grid = ((nwg + 8 * XG - 1) / (8 * XG)) * (8 * XG);
+    const float ms = time_it([&] { hipLaunchKernelGGL((colread_dwstore<G>), dim3(grid), dim3(G * 256), 0, 0, t1, re, im, M, P, ncols); });
+    printf("colread  ILV=1 G=%d dword plane stores (no final exchange): %7.1f us  read+write %6.0f GB/s\n", G, ms * 1e3, 2.0 * M * ncols * 16 / (ms * 1e-3) / 1e9);
+}
+
 template <int ILV, int SEQ>
 __global__ void __launch_bounds__(256) rowwrite(const uint4* __restrict__ x, float4* __restrict__ t1, int M, int P, int Cb, int delay_ns) {
     // M row pairs; input: 2 rows of 8192 bf16 per pair = 32 KB = 2048 uint4 -> 8 per thread
@@ -121,6 +152,8 @@ int main() {
     run_colread<1, 1>(t1, re, im, M, P, ncols);
     run_colread<1, 2>(t1, re, im, M, P, ncols);
     run_colread<1, 4>(t1, re, im, M, P, ncols);
+    run_colread_dw<1>(t1, re, im, M, P, ncols);
+    run_colread_dw<2>(t1, re, im, M, P, ncols);
     run_colread<2, 1>(t1, re, im, M, P, ncols);
     run_colread<2, 2>(t1, re, im, M, P, ncols);
     run_colread<4, 1>(t1, re, im, M, P, ncols);
