@@ -524,14 +524,18 @@ template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::i
 #ifndef SM_DIAG_NOFFT
 #define SM_DIAG_NOFFT 0
 #endif
-template <class P, bool PACK = true, int DIAG = 0, class Ex, class StT, class NatScatter, class FinGather>
-SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather) {
+struct NoHook { template <class C> SM_HD void operator()(C) const {} };
+// after_nat(comp_c): called once per component between the barrier behind the natural scatter and the next one - LDS
+// holds the natural-order values of that component and may be READ (a work-group level hook: it may run collectives)
+template <class P, bool PACK = true, int DIAG = 0, class Ex, class StT, class NatScatter, class FinGather, class AfterNat = NoHook>
+SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather, AfterNat after_nat = AfterNat{}) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
     if constexpr ((SM_DIAG_NOFFT & DIAG) != 0) {
         static_for<0, 2>([&](auto comp_c) {
             ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
             ex.sync();
+            after_nat(comp_c);
             ex.each(st, [&](int tid, S& s) { fin_gather(tid, s, comp_c); });
             ex.sync();
         });
@@ -543,6 +547,11 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
             constexpr int comp = decltype(comp_c)::value;
             ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
             ex.sync();
+            if constexpr (!std::is_same<AfterNat, NoHook>::value) {
+                SM_SCHED_FENCE();
+                after_nat(comp_c);              // (before the gather: the pass's 32 values are not live yet)
+                SM_SCHED_FENCE();
+            }
             ex.each(st, [&](int tid, S& s) {
                 pass_gather<P::radix(0)>(comp_of<comp>(s), lds + (tid / T) * LF, N, T, tid % T);
             });
@@ -580,6 +589,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
                 const float* l = lds + (tid / T) * LF;
                 SM_RADIX_SWITCH(pl.radix[0], pass_gather<RX>(comp_of<comp>(s), l, N, T, tid % T));
             });
+            after_nat(comp_c);
             ex.sync();
         });
         int Ns = 1;

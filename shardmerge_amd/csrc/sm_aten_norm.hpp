@@ -52,16 +52,9 @@
 // zero) reproduces the reference's norms to 2e-6 where exact norms are off by 2e-4 (4096^2;
 // oracle/aten_norm_model_probe.py).
 #pragma once
-#include "sm_kernels.hpp"
+#include "sm_kernels.hpp"        // (brings sm_aten_core.hpp: AtenSum, the chain evaluation, the fused row summaries)
 
 namespace smhip {
-
-constexpr int ATEN_LANES = 8;                  // Vectorized<float>::size() of ATen's AVX2 build
-constexpr int ATEN_THREADS = 256;
-constexpr int ATEN_ROWS_PER_THREAD = 32;       // rows of 8 elements per thread
-constexpr int ATEN_CHUNK_ROWS = ATEN_THREADS * ATEN_ROWS_PER_THREAD;      // 8192 rows = 65536 elements
-constexpr int ATEN_MAX_SIGS = 16;
-constexpr int ATEN_NO_EXP = -32768;
 
 // a stream of rows of 8 values
 struct AtenSrc {
@@ -198,30 +191,8 @@ SM_HD void aten_acc_add(AtenAcc& s, float x, double scale) {
     s.B0 += tie & (s.A ^ s.B0) & 1u;
     s.B1 += tie & (1u ^ s.A ^ s.B1) & 1u;
 }
-// f(m) = m + A + (m & 1 ? B1 : B0); pA = A & 1 rides in bit 31 of B1p; A = +inf: no summary ("stop")
-struct AtenSum { double A; uint32_t B0, B1p; };
-SM_HD AtenSum aten_sum_identity() { AtenSum r; r.A = 0.0; r.B0 = 0u; r.B1p = 0u; return r; }
-SM_HD AtenSum aten_sum_stop() { AtenSum r; r.A = INFINITY; r.B0 = 0u; r.B1p = 0u; return r; }
 SM_HD AtenSum aten_sum_of(const AtenAcc& a) {
     AtenSum r; r.A = (double)a.A; r.B0 = a.B0; r.B1p = (a.B1 & 0x7fffffffu) | ((a.A & 1u) << 31); return r;
-}
-SM_HD AtenSum aten_compose(const AtenSum& l, const AtenSum& r) {      // l first, then r
-    const uint32_t pl = l.B1p >> 31, lb1 = l.B1p & 0x7fffffffu;
-    const uint32_t pr = r.B1p >> 31, rb1 = r.B1p & 0x7fffffffu;
-    const uint32_t mid0 = (pl ^ l.B0) & 1u, mid1 = (1u ^ pl ^ lb1) & 1u;
-    AtenSum o;
-    o.A = l.A + r.A;
-    o.B0 = l.B0 + (mid0 ? rb1 : r.B0);
-    const uint32_t b1 = lb1 + (mid1 ? rb1 : r.B0);
-    o.B1p = (b1 & 0x7fffffffu) | ((pl ^ pr) << 31);
-    return o;
-}
-SM_HD double aten_apply(double m, uint32_t odd, const AtenSum& f) {
-    return m + f.A + (double)(odd ? (f.B1p & 0x7fffffffu) : f.B0);
-}
-SM_HD double aten_pow2(int e) {                 // 2^e as a double, -1022 <= e <= 1023
-    const unsigned long long b = (unsigned long long)(1023 + e) << 52;
-    double d; memcpy(&d, &b, 8); return d;
 }
 // S normal and not tiny: its binade e, its mantissa m (2^23 <= m < 2^24)
 SM_HD bool aten_split(float S, int& e, uint32_t& m) {
@@ -335,15 +306,6 @@ struct AtenPartParams {
     AtenSum* grp;               // [nsig][nchunks][8][2][32]: the same per group of 256 rows (8 threads)
     int* epred;                 // [nsig][nchunks][8]
 };
-constexpr int ATEN_GROUPS = 32;                 // groups of 8 threads = 256 rows per chunk
-constexpr int ATEN_GROUP_ROWS = ATEN_CHUNK_ROWS / ATEN_GROUPS;
-SM_HD int aten_exp_of(double v) {               // floor(log2 v) for a normal v > 0, else ATEN_NO_EXP
-    unsigned long long b; memcpy(&b, &v, 8);
-    const int ex = (int)((b >> 52) & 0x7ffu);
-    if ((b >> 63) || ex == 0 || ex == 0x7ff) return ATEN_NO_EXP;
-    const int e = ex - 1023;
-    return (e < -100 || e > 127) ? ATEN_NO_EXP : e;
-}
 // both candidates from one multiply: `fine` works in the ulp of binade e - 1 (scale_fine = 2^(24 - e)),
 // `coarse` in that of binade e.  y / u_coarse = (q1 + fr1) / 2 with q1 = floor(y / u_fine):
 // above half-way <=> q1 odd and fr1 > 0, half-way <=> q1 odd and fr1 == 0.
@@ -367,41 +329,9 @@ SM_HD void aten_acc_add2(AtenAcc& coarse, AtenAcc& fine, float x, double scale_f
         coarse.B1 += tie & (1u ^ coarse.A ^ coarse.B1) & 1u;
     }
 }
-// The same summary, EVALUATED instead of derived (round 4).  A step's increment of m = S / u depends on the running
-// sum only through its binade (u) and its parity (a tie goes to the even neighbour), and the parity after the step
-// follows from the parity before it: by induction the total increment D of a run depends on the START parity alone.
-// Two real chains of fmas over the run - one from m = 2^23 (even), one from m = 2^23 + 1 (odd) in the predicted
-// binade - therefore give D0 = A + B0 and D1 = A + B1 exactly, with the hardware's own rounding: one v_pk_fma_f32 per
-// element and candidate where the derivation above takes ~20 instructions, half of them in double precision.  A chain
-// that leaves the binade (an outlier, Inf, NaN) voids the summary, as an A >= 2^24 did.
-SM_HD vf2 aten_chain_start(int e) {
-    const uint32_t b = (uint32_t)(e + 127) << 23;
-    return mk2(u2f(b), u2f(b + 1u));
-}
-SM_HD void aten_chain_add(vf2& s, float y) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const vf2 yy = mk2(y, y);
-    s = __builtin_elementwise_fma(yy, yy, s);
-#else
-    s.x = std::fmaf(y, y, s.x); s.y = std::fmaf(y, y, s.y);
-#endif
-}
-SM_HD AtenSum aten_chain_sum(vf2 s, int e) {
-    const uint32_t b = (uint32_t)(e + 127) << 23;
-    const uint32_t f0 = f2u(s.x), f1 = f2u(s.y);
-    if ((f0 >> 23) != (b >> 23) || (f1 >> 23) != (b >> 23)) return aten_sum_stop();      // left the binade (or Inf / NaN)
-    const uint32_t d0 = f0 - b, d1 = f1 - (b + 1u);
-    const uint32_t a = d0 < d1 ? d0 : d1;
-    AtenSum r; r.A = (double)a; r.B0 = d0 - a; r.B1p = ((d1 - a) & 0x7fffffffu) | ((a & 1u) << 31);
-    return r;
-}
 // The chunk goes through LDS in ATEN_STAGES stages of 8 rows per thread: the loads are coalesced (8
 // consecutive threads fetch 8 consecutive rows), each thread then reads ITS 8 rows back - a thread's
 // rows must be consecutive for its summary to mean anything.
-constexpr double ATEN_LAG_MARGIN = 0.08;        // how far below the estimated prefix the running sum is allowed for (its bias is
-                                                // -3 % of the sum at 235 M elements; beyond the margin a chunk is walked cooperatively)
-constexpr double ATEN_LEAD_MARGIN = 0.02;       // ... and how far above (lattice data round UP on balance; the estimate
-                                                // comes from a sample)
 #ifndef SM_ATEN_STAGE_ROWS
 #define SM_ATEN_STAGE_ROWS 4
 #endif
@@ -594,6 +524,46 @@ SM_HD void k_aten_part(Ex& ex, const AtenPartParams& p) {
         });
         ex.sync();
     }
+}
+
+// ---- k_aten_rec: chunk summaries from the group summaries the row pass left (AtenFuse, sm_aten_core.hpp) ----------
+struct AtenRecParams {
+    int nsig;
+    size_t nchunks;
+    const double* prefix;
+    const AtenSum* grp;
+    AtenSum* rec;
+    int* epred;
+    size_t groups;              // groups of 256 rows-of-8 each signal has (those behind it are identities)
+};
+template <class Ex>
+SM_HD void k_aten_rec(Ex& ex, const AtenRecParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const size_t total = (size_t)p.nsig * p.nchunks * 16;
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t i = (size_t)ex.bid() * ATEN_THREADS + tid;
+        if (i >= total) return;
+        const int cand = (int)(i & 1);
+        const size_t slot = i >> 1;                                  // (sig * nchunks + chunk) * 8 + lane
+        const size_t chunk = (slot / 8) % p.nchunks;
+        const int ep = aten_exp_of(p.prefix[slot] * (1.0 + ATEN_LEAD_MARGIN));
+        const size_t g0 = chunk * ATEN_GROUPS;
+        const int ngr = g0 >= p.groups ? 0 : (p.groups - g0 < (size_t)ATEN_GROUPS ? (int)(p.groups - g0) : ATEN_GROUPS);
+        AtenSum run = aten_sum_identity();
+        if (ep != ATEN_NO_EXP) {
+            const AtenSum* gs = p.grp + (slot * 2 + cand) * ATEN_GROUPS;
+            for (int g = 0; g < ngr; g += 8) {                       // 8 records in flight, composed in order
+                AtenSum v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = g + u < ngr ? gs[g + u] : aten_sum_identity();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) run = aten_compose(run, v[u]);
+            }
+        }
+        p.rec[slot * 2 + cand] = run;
+        if (cand == 0) p.epred[slot] = ep;
+    });
 }
 
 // ---- k_aten_walk: one work-group per (signal, lane) -------------------------------------------

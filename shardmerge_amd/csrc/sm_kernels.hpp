@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "fft_engine.hpp"
+#include "sm_aten_core.hpp"
 
 namespace smhip {
 
@@ -191,6 +192,8 @@ struct FftState {
     float xr[EREG];
     float xi[EREG];
     double red[4];
+    uint32_t fd[4], fr[4];     // the row pass's fused torch.norm summaries (aten_fused_rows); dead everywhere else
+    int fep[2];                // ... and the predicted binades of this thread's group (per component)
 };
 
 constexpr int LDS_SCRATCH_FLOATS = 64 * 4;   // reduction scratch at the start of LDS
@@ -245,6 +248,8 @@ struct F1Params {
     size_t slab_elems;     // float4 per k1 slab of T1
     const cf2* twR;        // exp(-2 pi i j / R), j < R
     F1Sigs sigs;           // k_f1 / k_f1q: several signals in one launch
+    AtenFuse fuse;         // norm_mode = reference_cpu: the deltas' torch.norm summaries come out of this pass (prefix = null: off)
+    int fuse_rowpair;      // 1: signal = the launch's signal index, matrix row = 2 * unit + component; 0: signal = component (K = 2)
 };
 
 template <class P> constexpr bool f1_full_batch() {
@@ -286,6 +291,24 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
     // static plans are launched only when the 16-byte vector path applies (host checks),
     // so the element-wise path is not even compiled into them
     const bool vec = P::is_static ? true : (p.vec != 0);
+    // norm_mode = reference_cpu, fused summaries: which (signal, matrix row) region g holds in component comp
+    auto fuse_where = [&](int comp) {
+        return [&, comp](int g, int& sig, long long& mrow) {
+            const int row = bid * p.nb + g;
+            if (row >= p.R) return false;
+            if (p.fuse_rowpair) { sig = sig_; mrow = 2LL * row + comp; }
+            else { sig = comp; mrow = row; if (comp == 1 && !sgB.x) return false; }
+            return true;
+        };
+    };
+    if constexpr (P::is_static) {
+        if constexpr (aten_fusable(P::N, P::T)) {
+            if (p.fuse.prefix) ex.each(st, [&](int tid, FftState& s) {
+                s.fep[0] = aten_fused_ep<P::N, P::T>(p.fuse, tid, fuse_where(0));
+                s.fep[1] = aten_fused_ep<P::N, P::T>(p.fuse, tid, fuse_where(1));
+            });
+        }
+    }
 
     ex.each(st, [&](int tid, FftState& s) {
         const int g = tid / T, t = tid % T;
@@ -486,6 +509,16 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
                     if (!sgB.x) o[2 * u + 1] = 0.f;
                 }
             }
+        },
+        [&](auto comp_c) {
+            // norm_mode = reference_cpu: the torch.norm summaries of the deltas that now sit in LDS in natural order
+            constexpr int comp = decltype(comp_c)::value;
+            if constexpr (P::is_static) {
+                if constexpr (aten_fusable(P::N, P::T)) {
+                    if (p.fuse.prefix)
+                        aten_fused_rows<P::N, P::T>(ex, st, p.fuse, lds, LF, fuse_where(comp), [](FftState& s) { return s.fep[comp]; });
+                }
+            }
         });
 
     ex.each(st, [&](int tid, FftState& s) {
@@ -577,6 +610,9 @@ SM_HD void k_f1q(Ex& ex, const F1Params& p) {
     const size_t slabstride = p.slab_elems;                      // slab-major: [k1][unit][bin]
 
     ex.each(st, [&](int, F1QState& s) { s.red[0] = 0.0; s.red[1] = 0.0; });
+    // (no fused torch.norm summaries here, unlike k_f1: this kernel is one 1024-thread work-group per CU whose transform
+    //  phase is fully exposed - measured on MI355X the summaries cost it +514 us per 28672 x 8192 K = 3 launch, more than
+    //  the separate summary pass they would replace (454 us); the folded shapes keep k_aten_part)
 
     // Register budget: a 1024-thread work-group has 128 VGPRs per thread.  The operands are
     // therefore loaded one at a time, straight into the first LDS scatter (a in the pass of the

@@ -193,6 +193,7 @@ SM_KERNEL_TAG(KTranspose, TransposeParams, "transpose", k_transpose(ex, p))
 SM_KERNEL_TAG_LB(KAtenPre, AtenPreParams, "aten_norm_pre", k_aten_pre<0>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenPreC, AtenPreParams, "aten_norm_pre", k_aten_pre<1>(ex, p), 256, 4)
 SM_KERNEL_TAG_LB(KAtenScan, AtenScanParams, "aten_norm_scan", k_aten_scan(ex, p), 256, 4)
+SM_KERNEL_TAG_LB(KAtenRec, AtenRecParams, "aten_norm_rec", k_aten_rec(ex, p), 256, 4)
 #ifndef SM_ATEN_PART_WAVES
 #define SM_ATEN_PART_WAVES 3
 #endif
@@ -206,7 +207,7 @@ SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finis
 // Every kernel is instantiated in smhip_side.hip (one group per translation unit, -DSM_SIDE_GROUP=<g>) or, the
 // static-plan transforms, in smhip_inst.hip; smhip_hip.hip holds host code only.  The build parallelises and a
 // change to the host orchestration does not recompile a single kernel.
-#define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenPart16) X(KAtenPart32) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
+#define SM_SIDE_KERNELS_0(X) X(KAtenPre) X(KAtenPreC) X(KAtenScan) X(KAtenRec) X(KAtenPart16) X(KAtenPart32) X(KAtenPart) X(KAtenPartC) X(KAtenWalk) X(KAtenWalkC) X(KAtenFinish)
 #define SM_SIDE_KERNELS_1(X) X(KF2R1) X(KI1R1) X(KPublish) X(KHist) X(KScan) X(KSelect2) X(KSelect2Cull) X(KBlendSel) \
     X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials) X(KClassEmf)
 #define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
@@ -689,9 +690,11 @@ class Pipeline {
         if (rc) return rc;
         p.a = a; p.b = b; p.R = g.R; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = g.ilv;
         p.sigs.n = 0;
+        p.fuse.prefix = nullptr; p.fuse.grp = nullptr; p.fuse.nchunks = 0; p.fuse.sig0 = 0; p.fuse_rowpair = 0;
         p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)g.C;
         p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        if (fused_.armed && p.vec && g.batch == 1 && g.rough == 1) { p.fuse = fused_.af; p.fuse_rowpair = 0; fused_.used = true; }
         p.t1 = (cf4*)t1_.p;
         p.partials = d_part();
         p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g);
@@ -755,11 +758,15 @@ class Pipeline {
         if (sig.base) b.base = (const char*)sig.base + (size_t)g.C * dt_size(sig.dtype);
         p.a = a; p.b = b; p.R = g.R / 2; p.C = g.C; p.Cb = g.C / 2 + 1; p.pitch4 = g.pitch4; p.ilv = F2S_ILV;
         p.sigs.n = 0;
+        p.fuse.prefix = nullptr; p.fuse.grp = nullptr; p.fuse.nchunks = 0; p.fuse.sig0 = 0; p.fuse_rowpair = 0;
         const int nm = multi ? multi->n : 1;
         if (multi && (blue || nm < 2 || nm > F1_MAX_SIGS)) return SMHIP_ERR_ARG;
         p.nb = blue ? 1 : std::max(1, 256 / p.plan.T);
         p.row_stride = (size_t)2 * g.C;
         p.vec = !blue && (g.C % 8 == 0) && aligned16(a.x) && aligned16(a.base) && aligned16(b.x) && aligned16(b.base);
+        if (fused_.armed && p.vec && g.batch == 1 && g.rough == 1) {
+            p.fuse = fused_.af; p.fuse.sig0 = multi ? 0 : fused_.next_sig; p.fuse_rowpair = 1; fused_.used = true;
+        }
         p.t1 = (cf4*)(t1buf ? t1buf : t1_.p);
         p.partials = partials ? partials : d_part();
         p.R2 = 0; p.rowpair = 0; p.Rcol = g.R; p.twR = nullptr; p.slab_elems = fold_slab_elems(g, true);
@@ -1639,6 +1646,85 @@ class Pipeline {
         be.template launch<KAtenFinish>(1, 64, LDS_SCRATCH_FLOATS * 4, f, stream);
         return true;
     }
+    // ---- reference_cpu, fused: the forward row pass summarises the deltas it forms (AtenFuse, sm_aten_core.hpp) ------
+    // begin_fused_norms(): sampled prefix + scan (the binade predictions), buffers; the row pass launched next writes
+    // the group summaries; finish_fused_norms(): chunk summaries, walker, finish -> mail_->snorm after the next sync.
+    bool fused_done_ = false;
+    struct FusedNorms {
+        bool armed = false, used = false;
+        AtenFuse af;
+        int nsig = 0, next_sig = 0;
+        size_t nchunks = 0, groups = 0;
+        AtenSum* rec = nullptr; int* epred = nullptr;
+        AtenSrc srcs[ATEN_MAX_SIGS];
+    } fused_;
+    bool fuse_norms = true;            // test hook "fuse_norms" = 0: the separate summary pass (k_aten_part) as before
+    // the row plan of this geometry summarises in its natural scatter: a static plan, whole groups of 256 rows-of-8
+    // per matrix row, one wave per group
+    bool fusable_rows(const Geo& g) {
+        FftPlanDev pl;
+        // (not the folded row pass: k_f1q's transform phase is fully exposed and the summaries cost it more than the
+        //  separate pass they replace - see k_f1q)
+        if (g.batch != 1 || g.rough != 1 || g.full || g.fold != 1 || row_bluestein(g.C) || get_plan(g.C, pl) || !is_static_plan(pl)) return false;
+        return aten_fusable(g.C, pl.T);
+    }
+    bool begin_fused_norms(const Geo& g, const std::vector<Slot>& stack, size_t n) {
+        fused_.armed = fused_.used = false;
+        const int k = (int)stack.size();
+        if (!fuse_norms || aten_serial || k < 1 || k > ATEN_MAX_SIGS || !fusable_rows(g) || (n % (8 * ATEN_GROUP_ROWS)) != 0) return false;
+        const size_t rows = n / 8;
+        const size_t nchunks = (rows + ATEN_CHUNK_ROWS - 1) / ATEN_CHUNK_ROWS;
+        if (nchunks < 2 || nchunks * k > (size_t)1 << 30) return false;       // (one chunk: the walker works from the data)
+        for (int i = 0; i < k; ++i) {
+            const SigDesc& sg = stack[i].sig;
+            if (!sg.x || !sg.base || sg.dtype == DT_F32 || sg.prescale != 1.f || sg.dtype != stack[0].sig.dtype ||
+                !aligned16(sg.x) || !aligned16(sg.base)) return false;
+            memset(&fused_.srcs[i], 0, sizeof(AtenSrc));
+            fused_.srcs[i].kind = 0; fused_.srcs[i].sig = sg; fused_.srcs[i].n = n; fused_.srcs[i].C = -1;
+        }
+        const size_t pre_bytes = round_up((size_t)k * nchunks * 8 * sizeof(double), 256);
+        const size_t rec_bytes = round_up((size_t)k * nchunks * 16 * sizeof(AtenSum), 256);
+        const size_t grp_bytes = round_up((size_t)k * nchunks * 16 * ATEN_GROUPS * sizeof(AtenSum), 256);
+        const size_t ep_bytes = round_up((size_t)k * nchunks * 8 * sizeof(int), 256);
+        if (ensure(aten_, ATEN_HEAD_BYTES + pre_bytes + rec_bytes + grp_bytes + ep_bytes)) return false;
+        char* basep = (char*)aten_.p + ATEN_HEAD_BYTES;
+        double* pre = (double*)basep;
+        AtenPreParams a;
+        a.nsig = k; a.nchunks = nchunks; a.pre = pre;
+        for (int i = 0; i < ATEN_MAX_SIGS; ++i) a.src[i] = fused_.srcs[i < k ? i : 0];
+        be.template launch<KAtenPre>((int)(nchunks * k), ATEN_THREADS, LDS_SCRATCH_FLOATS * 4, a, stream);
+        AtenScanParams sc;
+        sc.pre = pre; sc.nchunks = nchunks;
+        be.template launch<KAtenScan>(k, ATEN_THREADS, (LDS_SCRATCH_FLOATS + 2 * 32 * 8) * 4, sc, stream);
+        fused_.af.prefix = pre; fused_.af.grp = (AtenSum*)(basep + pre_bytes + rec_bytes); fused_.af.nchunks = nchunks; fused_.af.sig0 = 0;
+        fused_.rec = (AtenSum*)(basep + pre_bytes); fused_.epred = (int*)(basep + pre_bytes + rec_bytes + grp_bytes);
+        fused_.nsig = k; fused_.nchunks = nchunks; fused_.groups = rows / ATEN_GROUP_ROWS; fused_.next_sig = 0;
+        fused_.armed = true;
+        return true;
+    }
+    // behind the row pass(es): false when no row pass took the summaries up (the caller falls back to the separate pass)
+    bool finish_fused_norms() {
+        const bool ok = fused_.armed && fused_.used;
+        fused_.armed = false;
+        if (!ok) return false;
+        const int k = fused_.nsig;
+        AtenRecParams r;
+        r.nsig = k; r.nchunks = fused_.nchunks; r.prefix = fused_.af.prefix; r.grp = fused_.af.grp; r.rec = fused_.rec;
+        r.epred = fused_.epred; r.groups = fused_.groups;
+        const size_t total = (size_t)k * fused_.nchunks * 16;
+        be.template launch<KAtenRec>((int)((total + ATEN_THREADS - 1) / ATEN_THREADS), ATEN_THREADS, LDS_SCRATCH_FLOATS * 4, r, stream);
+        AtenWalkParams w;
+        w.nsig = k; w.nchunks = fused_.nchunks; w.rec = fused_.rec; w.grp = fused_.af.grp; w.epred = fused_.epred;
+        w.lanes = d_aten_lanes(); w.stats = d_aten_stats();
+        for (int i = 0; i < ATEN_MAX_SIGS; ++i) w.src[i] = fused_.srcs[i < k ? i : 0];
+        be.template launch<KAtenWalk>(k * 8, ATEN_THREADS, (LDS_SCRATCH_FLOATS + ATEN_WALK_LDS_FLOATS) * 4, w, stream);
+        AtenFinishParams f;
+        f.nsig = k; f.lanes = d_aten_lanes(); f.out = d_aten_out(); f.mail = mail_->snorm;
+        for (int i = 0; i < ATEN_MAX_SIGS; ++i) f.src[i] = fused_.srcs[i < k ? i : 0];
+        be.template launch<KAtenFinish>(1, 64, LDS_SCRATCH_FLOATS * 4, f, stream);
+        return true;
+    }
+
     // the delta / fp32 norms of `k` signals of n elements each -> out[] (one sync)
     bool run_serial_norms(const SigDesc* sigs, int k, size_t n, double* out) {
         if (k < 1 || k > 16) return false;
@@ -1722,6 +1808,7 @@ class Pipeline {
                     sp.partials = d_part() + (size_t)i * 2 * gq; sp.nparts = gq; sp.out = mail_->norm2 + 2 * i;
                     be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
                 }
+                fused_done_ = finish_fused_norms();
                 be.sync(stream);
                 for (int i = 0; i < k; ++i) {
                     stack[i].norm = std::sqrt(mail_->norm2[2 * i] + mail_->norm2[2 * i + 1]);
@@ -1732,12 +1819,14 @@ class Pipeline {
             if (rc != SMHIP_ERR_ARG) return rc;
         }
         for (int i = 0; i < k; ++i) {
+            fused_.next_sig = i;
             if ((rc = run_f1_rowpairs(g, stack[i].sig, rowspec_[i].p, d_part() + poff, &grids[i]))) return rc;
             SumPartialsParams sp;
             sp.partials = d_part() + poff; sp.nparts = grids[i]; sp.out = mail_->norm2 + 2 * i;
             be.template launch<KSumPartials>(1, 1024, LDS_SCRATCH_FLOATS * 4, sp, stream);
             poff += 2 * (size_t)grids[i];
         }
+        fused_done_ = finish_fused_norms();
         be.sync(stream);
         for (int i = 0; i < k; ++i) {
             stack[i].norm = std::sqrt(mail_->norm2[2 * i] + mail_->norm2[2 * i + 1]);      // even rows + odd rows
@@ -1862,9 +1951,15 @@ class Pipeline {
         int f1_grid = -1;
         bool f1_ready = false;
         bool ref_started = false;          // reference_cpu: the deltas' torch.norm emulation runs beside the row passes
+        fused_done_ = false;
+        fused_.armed = false;
         if (d.k == 2) {
-            if (ref_norms) ref_started = begin_delta_ref_norms(stack, n);
+            // reference_cpu: the row pass summarises its deltas for the torch.norm emulation when its plan can
+            // (begin_fused_norms), else the separate summary pass runs in front of it with the walker beside it
+            const bool fusing = ref_norms && begin_fused_norms(g, stack, n);
+            if (ref_norms && !fusing) ref_started = begin_delta_ref_norms(stack, n);
             rc = run_f1(g, stack[0].sig, stack[1].sig, f1_grid);
+            if (fusing) ref_started = finish_fused_norms();
             end_delta_ref_norms();
             if (rc) return rc;
             double na, nb;
@@ -1872,7 +1967,9 @@ class Pipeline {
             stack[0].norm = na; stack[1].norm = nb;
             f1_ready = true;
         } else if (spectral_ok && all_aligned && (C % 8 == 0) && (size_t)d.k * 2 * (size_t)(g.R / 2 + 8) * g.batch <= PART_DOUBLES &&
-                   ((ref_started = ref_norms && begin_delta_ref_norms(stack, n)), rows_first(g, stack) == SMHIP_OK)) {
+                   ((ref_started = ref_norms && !begin_fused_norms(g, stack, n) && begin_delta_ref_norms(stack, n)),
+                    rows_first(g, stack) == SMHIP_OK)) {
+            if (fused_done_) ref_started = true;        // (the row passes took the summaries with them; rows_first has synced)
             // K >= 3: every delta's ROWS are transformed up front, one signal at a time (row pairs);
             // the norms come with it (no separate pass over the inputs), and whichever deltas the
             // pairing puts together only need their column passes afterwards
@@ -1890,7 +1987,8 @@ class Pipeline {
                 }
             }
         }
-        if (ref_started && d.k != 2) { end_delta_ref_norms(); be.sync(stream); }      // (K = 2: joined in front of read_norms' sync)
+        fused_.armed = false;
+        if (ref_started && d.k != 2 && !fused_done_) { end_delta_ref_norms(); be.sync(stream); }      // (K = 2: joined in front of read_norms' sync)
         if (ref_started) {
             for (int i = 0; i < d.k; ++i) stack[i].norm = (double)mail_->snorm[i];
         } else if (ref_norms) {

@@ -26,6 +26,14 @@ struct DeviceExec {
     __device__ __forceinline__ void global_atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
     __device__ __forceinline__ void global_atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 
+    // dst(lane)[i] = src(lane + DELTA)[i], i < N dwords, inside the 64-lane wave (lanes past its end keep their own)
+    template <int DELTA, int N, class S, class Src, class Dst>
+    __device__ __forceinline__ void wave_shift_down(State<S>& st, Src src, Dst dst) {
+        const uint32_t* a = src(st.s);
+        uint32_t* b = dst(st.s);
+#pragma unroll
+        for (int i = 0; i < N; ++i) b[i] = (uint32_t)__shfl_down((int)a[i], DELTA, 64);
+    }
     // sum NV doubles (State::red) over the work-group; f(total) runs on thread 0.
     // Uses the first LDS_SCRATCH_FLOATS of LDS; ends with a barrier.
     template <int NV, class S, class F>

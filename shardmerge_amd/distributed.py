@@ -129,9 +129,7 @@ def _tensor_meta(index: LocalModelIndex, uri: str, shard_file: str) -> Dict[str,
     return out
 
 
-_ST_DTYPES = {"BF16": torch.bfloat16, "F16": torch.float16, "F32": torch.float32}
-_ST_NAMES = {torch.bfloat16: "BF16", torch.float16: "F16", torch.float32: "F32", torch.float64: "F64"}
-_ST_SIZE = {"BF16": 2, "F16": 2, "F32": 4, "F64": 8}
+from .stformat import ST_DTYPES as _ST_DTYPES, ST_NAMES as _ST_NAMES, ST_SIZE as _ST_SIZE, shard_header  # noqa: E402,F401
 
 
 def init_process_group(device: torch.device):
@@ -150,27 +148,6 @@ def init_process_group(device: torch.device):
 
 
 # ---- output shards written in place ------------------------------------------------------------------------
-def shard_header(entries: Sequence[Tuple[str, str, Sequence[int]]], metadata: Dict[str, str]) -> Tuple[bytes, Dict[str, Tuple[int, int]]]:
-    """The bytes in front of a safetensors payload (8-byte length + JSON padded to 8 bytes) for tensors
-    (name, dtype string, shape), laid out as safetensors' own writer does it (by dtype, widest first, then by
-    name - tests/test_host_logic.py pins the bytes against safetensors.torch.save_file), and the payload
-    offsets (begin, end) per name."""
-    rank_of_dtype = {"F64": 0, "F32": 1, "BF16": 2, "F16": 2}
-    order = sorted(entries, key=lambda e: (rank_of_dtype.get(e[1], 9), e[0]))
-    doc: Dict[str, object] = {"__metadata__": dict(metadata)}
-    offsets, pos = {}, 0
-    for name, dt, shape in order:
-        n = _ST_SIZE[dt]
-        for d in shape:
-            n *= int(d)
-        doc[name] = {"dtype": dt, "shape": [int(d) for d in shape], "data_offsets": [pos, pos + n]}
-        offsets[name] = (pos, pos + n)
-        pos += n
-    blob = json.dumps(doc, separators=(",", ":")).encode()
-    blob += b" " * ((8 - len(blob) % 8) % 8)
-    return len(blob).to_bytes(8, "little") + blob, offsets
-
-
 def _read_metadata(path: Path):
     try:
         with open(path, "rb") as fh:

@@ -34,6 +34,7 @@ _ST_DTYPES = {
 }
 
 Request = Tuple[str, str]          # (model uri, tensor name)
+_READ_PIECE = 32 << 20
 
 
 class ShardFile:
@@ -52,17 +53,27 @@ class ShardFile:
         rec = self.entries[name]
         return rec["shape"], _ST_DTYPES[rec["dtype"]], rec["data_offsets"][1] - rec["data_offsets"][0]
 
-    def read_into(self, name: str, dst: torch.Tensor):
-        """dst: contiguous uint8 CPU tensor of exactly the payload size."""
+    def read_into(self, name: str, dst: torch.Tensor, pool: Optional[ThreadPoolExecutor] = None):
+        """dst: contiguous uint8 CPU tensor of exactly the payload size.  pool: the payload is read in 32 MB pieces
+        side by side (os.preadv releases the GIL; one thread copies ~8 GB/s out of the page cache)."""
         rec = self.entries[name]
         off0, off1 = rec["data_offsets"]
         view = memoryview(dst.numpy()).cast("B")
-        fd, pos, got = self.fh.fileno(), self.data_start + off0, 0
-        while got < off1 - off0:                       # positional reads: safe from several threads
-            k = os.preadv(fd, [view[got:got + (1 << 30)]], pos + got)
-            if not k:
-                raise IOError(f"short read of {name} in {self.path}")
-            got += k
+        fd, pos = self.fh.fileno(), self.data_start + off0
+
+        def piece(a: int, b: int):
+            got = a
+            while got < b:                             # positional reads: safe from several threads
+                k = os.preadv(fd, [view[got:min(b, got + (1 << 30))]], pos + got)
+                if not k:
+                    raise IOError(f"short read of {name} in {self.path}")
+                got += k
+        n = off1 - off0
+        if pool is None or n <= _READ_PIECE:
+            piece(0, n)
+            return
+        for f in [pool.submit(piece, a, min(n, a + _READ_PIECE)) for a in range(0, n, _READ_PIECE)]:
+            f.result()
 
     def close(self):
         self.fh.close()
@@ -89,6 +100,10 @@ class PrefetchLoader:
         self.bytes_read = 0
         self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SHARDMERGE_READ_THREADS", "4")),
                                        thread_name_prefix="shardmerge-read")
+        # ... and the pieces of one tensor's payload (a 28672 x 8192 bf16 tensor is 470 MB: one thread would copy it
+        # at a sixth of what the PCIe link takes)
+        self.piece_pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SHARDMERGE_READ_PIECE_THREADS", "12")),
+                                             thread_name_prefix="shardmerge-read-piece")
 
     # ---- producer ---------------------------------------------------------------------
     def start(self, schedule: Sequence[Sequence[Request]]):
@@ -113,7 +128,7 @@ class PrefetchLoader:
             host = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=self.on_gpu)[:nbytes]
         if nbytes:
             with iostats.timed("read", nbytes):          # (summed over the read threads)
-                f.read_into(name, host)
+                f.read_into(name, host, self.piece_pool)
         self.bytes_read += nbytes
         cpu = host.view(dtype).reshape(shape) if nbytes else torch.empty(shape, dtype=dtype)
         if not self.on_gpu:
@@ -197,6 +212,7 @@ class PrefetchLoader:
         if self.thread is not None:
             self.thread.join(timeout=30)
         self.pool.shutdown(wait=True)
+        self.piece_pool.shutdown(wait=True)
         for f in self.files.values():
             f.close()
         self.files.clear()

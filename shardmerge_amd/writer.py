@@ -23,7 +23,7 @@ from typing import Dict, Generator, List, Set, Tuple
 
 import torch
 
-from . import iostats
+from . import iostats, stformat
 from safetensors import safe_open
 from safetensors.torch import save_file
 
@@ -148,13 +148,35 @@ class ModelWriter:
             merged[k] = t
         ordered = {k: merged[k] for k in sorted(merged, key=lambda k: self._rank.get(k, len(self._rank)))}
         tmp = path.with_name(f".tmp-{path.name}")
-        with iostats.timed("save", sum(t.numel() * t.element_size() for t in ordered.values())):
-            save_file(ordered, str(tmp), metadata={"format": "pt"})
+        nbytes = sum(t.numel() * t.element_size() for t in ordered.values())
+        with iostats.timed("save", nbytes):
+            if all(t.dtype in stformat.ST_NAMES and t.is_contiguous() for t in ordered.values()):
+                # the file is laid out by hand (header bytes identical to safetensors' own writer, pinned by
+                # tests/test_distributed_gloo.py) and the tensors go from their pinned buffers straight to their
+                # offsets, several pieces at a time: save_file() serialises through one more copy on one thread
+                head, offsets = stformat.shard_header([(k, stformat.ST_NAMES[t.dtype], list(t.shape)) for k, t in ordered.items()],
+                                                      {"format": "pt"})
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    os.pwrite(fd, head, 0)
+                    os.ftruncate(fd, len(head) + nbytes)
+                    stformat.pwrite_tensors(fd, len(head), offsets, ordered, self._io_pool())
+                finally:
+                    os.close(fd)
+            else:
+                save_file(ordered, str(tmp), metadata={"format": "pt"})
         os.replace(tmp, path)                  # resume must never see a half-written shard
         with self._lock:
             for k in fresh:
                 self.written_shard_layers.add((name, k))
         logger.info(f"Wrote {len(fresh)} tensor(s) to shard {name}")
+
+    def _io_pool(self):
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get("SHARDMERGE_WRITE_THREADS", "8")),
+                                            thread_name_prefix="shardmerge-write")
+        return self._pool
 
     def _worker(self):
         while True:
@@ -193,6 +215,9 @@ class ModelWriter:
             self._jobs.put(None)
             self._thread.join()
             self._thread = None
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         self._raise_worker_error()
         missing = [(s, n) for s, names in self.shard_to_tensors.items() for n in names
                    if (s, n) not in self.written_shard_layers]

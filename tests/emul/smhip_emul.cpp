@@ -37,6 +37,15 @@ struct HostExec {
     void global_atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
     void global_atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
     void global_atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
+    template <int DELTA, int N, class S, class Src, class Dst> void wave_shift_down(State<S>& st, Src src, Dst dst) {
+        for (int t = 0; t < nt_; ++t) {
+            const int q = t + DELTA;
+            const int from = (q < nt_ && q / 64 == t / 64) ? q : t;
+            const uint32_t* a = src(st.v[from]);
+            uint32_t* b = dst(st.v[t]);
+            for (int i = 0; i < N; ++i) b[i] = a[i];
+        }
+    }
     template <int NV, class S, class F> void block_sum(State<S>& st, F&& f) {
         double tot[NV];
         for (int q = 0; q < NV; ++q) tot[q] = 0;

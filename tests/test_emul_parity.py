@@ -974,3 +974,40 @@ def test_k3_k4_within_the_reference_own_floor(engine, golden, case):
 def test_noise_model_seed_does_not_matter_beyond_the_floor(engine, golden):
     d01, d02, floor = pc.check_noise_seed_sensitivity(engine, golden, gi.FLOOR_CASES[0])
     print(f"two other seeds move the K = 3 output by {d01:.2e} / {d02:.2e}; the reference's own floor is {floor:.2e}")
+
+
+@pytest.mark.parametrize("k,shape,fold", [(2, (64, 2048), False), (2, (48, 4096), False), (3, (24, 8192), False),
+                                         (3, (16, 16384), False), (3, (8192, 2048), True)],
+                         ids=lambda v: str(v).replace(" ", ""))
+def test_row_pass_summarises_its_deltas_for_the_norm_emulation(engine, k, shape, fold):
+    """norm_mode = reference_cpu, round 4: the forward row pass (k_f1 / k_f1q, AtenFuse) evaluates the torch.norm chunk
+    summaries on the deltas it has just formed - two real fma chains per lane and candidate binade over the natural-order
+    row in LDS, composed in order across the wave - instead of a second pass over every finetune and base
+    (k_aten_part).  The norms stay torch.norm's BIT FOR BIT (reference functions.py:85, fast_fourier.py:152,209-210),
+    equal to the separate pass's, and the walker composes the chunks from those summaries (it is not walking the data)."""
+    from oracle import spectral_oracle as so
+    rows, cols = shape
+    base, fts = so.synthetic_layer(rows, cols, k, seed=4400 + rows + k)
+    torch_norms = [float((f.float() - base.float()).norm()) for f in fts]
+    if fold:
+        engine.ctx.debug_option("fold_min_rows", 8192)
+    engine.ctx.profile(True)
+    try:
+        got = {}
+        for fuse in (1, 0):
+            engine.ctx.debug_option("fuse_norms", fuse)
+            engine.ctx.profile_reset()
+            out, rep = engine.merge_layer(fts, [base] * k, so.ALPHAS[:k], base, norm_mode="reference_cpu")
+            names = set(engine.ctx.profile_table())
+            fused = bool(fuse) and not fold          # (the folded row pass k_f1q keeps the separate summary pass: see there)
+            assert ("aten_norm_rec" in names) == fused and ("aten_norm_part" in names) == (not fused), names
+            assert rep.delta_norms == torch_norms, (fuse, rep.delta_norms, torch_norms)
+            stats = [engine.ctx.debug_query(q) for q in ("aten_fast", "aten_group", "aten_slow")]
+            assert stats[0] + stats[1] > 0, stats            # chunks composed from summaries / crossed by group summaries
+            got[fuse] = (out.cpu(), stats)
+        assert torch.equal(got[0][0], got[1][0])
+        assert got[0][1] == got[1][1]                        # the walker finds the same summaries usable either way
+    finally:
+        engine.ctx.debug_option("fuse_norms", 1)
+        engine.ctx.debug_option("fold_min_rows", 0)
+        engine.ctx.profile(False)

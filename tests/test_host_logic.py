@@ -122,6 +122,26 @@ def test_writer_buffers_orders_and_resumes(tmp_path):
     w2.finalize()
 
 
+def test_writer_direct_shard_write_is_safetensors_own_bytes(tmp_path):
+    """The single-process writer lays a complete shard out by hand (header + tensors pwritten from their host buffers in
+    32 MB pieces on a thread pool): the file must be byte for byte what safetensors.torch.save_file writes (N2;
+    reference shard/writer.py:124-143 goes through save_file)."""
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(5)
+    names = ["model.embed_tokens.weight", "model.layers.0.a", "model.layers.0.b", "model.layers.0.norm"]
+    tensors = {names[0]: torch.randn(17, 8, generator=g), names[1]: torch.randn(300, 70, generator=g),
+               names[2]: torch.randn(5, generator=g), names[3]: torch.randn(2, 3, 4, generator=g)}
+    index = {"metadata": {}, "weight_map": {n: "s1" for n in names}}
+    for dtype in (torch.bfloat16, torch.float32, torch.float16):
+        out = tmp_path / f"o_{str(dtype).split('.')[-1]}"
+        w = ModelWriter(base_index=index, output_path=out, layer_order=names, output_astype=dtype)
+        for n in names:
+            w.add_tensor(n, tensors[n])
+        w.finalize()
+        save_file({n: tensors[n].to(dtype).contiguous() for n in names}, str(tmp_path / "ref"), metadata={"format": "pt"})
+        assert (out / "s1").read_bytes() == (tmp_path / "ref").read_bytes()
+
+
 def test_name_hash():
     h = name_hash("model_layer_weight")                       # reference test_fast_fourier.py:62-68
     assert h.startswith("mode_laye_weig::") and re.fullmatch(r"[0-9a-f]{8}", h.split("::")[1])

@@ -25,23 +25,30 @@ BLOCK = [("self_attn.q_proj.weight", 4096, 4096), ("self_attn.k_proj.weight", 10
          ("mlp.gate_proj.weight", 14336, 4096), ("mlp.up_proj.weight", 14336, 4096),
          ("mlp.down_proj.weight", 4096, 14336), ("input_layernorm.weight", 1, 4096),
          ("post_attention_layernorm.weight", 1, 4096)]
+BLOCK_70B = [("self_attn.q_proj.weight", 8192, 8192), ("self_attn.k_proj.weight", 1024, 8192),
+             ("self_attn.v_proj.weight", 1024, 8192), ("self_attn.o_proj.weight", 8192, 8192),
+             ("mlp.gate_proj.weight", 28672, 8192), ("mlp.up_proj.weight", 28672, 8192),
+             ("mlp.down_proj.weight", 8192, 28672), ("input_layernorm.weight", 1, 8192),
+             ("post_attention_layernorm.weight", 1, 8192)]
 SIGMA = (0.002, 0.003, 0.0025, 0.004)
 
 
-def write_models(root: Path, blocks: int, k: int, gen_device: str):
+def write_models(root: Path, blocks: int, k: int, gen_device: str, model: str = "llama3-8b"):
     storage = root / "storage"
     uris = ["org/base"] + [f"org/ft{i}" for i in range(1, k + 1)]
     g = torch.Generator(device=gen_device).manual_seed(1000)
     total = 0
+    block = BLOCK_70B if model == "llama3-70b" else BLOCK
+    hidden = block[0][2]
     for b in range(-1, blocks + 1):               # -1: embed shard, blocks: norm + lm_head shard
         if b == -1:
-            items = [("model.embed_tokens.weight", 2048, 4096)]
+            items = [("model.embed_tokens.weight", 2048, hidden)]
             shard = "model-embed.safetensors"
         elif b == blocks:
-            items = [("model.norm.weight", 1, 4096), ("lm_head.weight", 2048, 4096)]
+            items = [("model.norm.weight", 1, hidden), ("lm_head.weight", 2048, hidden)]
             shard = "model-head.safetensors"
         else:
-            items = [(f"model.layers.{b}.{n}", r, c) for n, r, c in BLOCK]
+            items = [(f"model.layers.{b}.{n}", r, c) for n, r, c in block]
             shard = f"model-{b:05d}.safetensors"
         base = {}
         for name, r, c in items:
@@ -79,6 +86,9 @@ def main():
     ap.add_argument("--root", default="/dev/shm/smcli")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b"],
+                    help="block shapes; llama3-70b with --k 3 is the metric's configuration (1.7 GB of bf16 per block and model)")
+    ap.add_argument("--runs", default="0,1,0,1", help="SHARDMERGE_PREFETCH value of each run")
     args = ap.parse_args()
     from shardmerge_amd.constants import tune_hip_queues
     tune_hip_queues()
@@ -87,12 +97,13 @@ def main():
         shutil.rmtree(root)
     root.mkdir(parents=True)
     t0 = time.time()
-    cfg_path, n_params = write_models(root, args.blocks, args.k, args.device if torch.cuda.is_available() else "cpu")
+    cfg_path, n_params = write_models(root, args.blocks, args.k, args.device if torch.cuda.is_available() else "cpu", args.model)
     print(f"# wrote {args.k + 1} models, {n_params / 1e6:.0f} M params each, in {time.time() - t0:.1f} s under {root}", file=sys.stderr)
 
     from shardmerge_amd.__main__ import run_merge
     from shardmerge_amd.config import MergeConfig
-    for prefetch in ("0", "1", "0", "1"):
+    from shardmerge_amd import iostats
+    for prefetch in args.runs.split(","):
         os.environ["SHARDMERGE_PREFETCH"] = prefetch
         out_dir = root / "merged"
         if out_dir.exists():
@@ -100,14 +111,24 @@ def main():
         config = MergeConfig.from_yaml(cfg_path)
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        iostats.snapshot(reset=True)
         t0 = time.time()
         asyncio.run(run_merge(config, args.device, clean_cache=False))
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         dt = time.time() - t0
-        print(json.dumps({"cli_merge": "end to end", "prefetch": prefetch == "1", "blocks": args.blocks, "k": args.k,
-                          "params": n_params, "seconds": round(dt, 3), "merged_GBps": round(2.0 * n_params / dt / 1e9, 3),
-                          "input_GB": round(2.0 * n_params * (args.k + 1) / 1e9, 2)}))
+        st = iostats.snapshot(reset=True)
+        in_gb, out_gb = 2.0 * n_params * (args.k + 1) / 1e9, 2.0 * n_params / 1e9
+        rec = {"cli_merge": "end to end", "model": args.model, "prefetch": prefetch == "1", "blocks": args.blocks, "k": args.k,
+               "params": n_params, "seconds": round(dt, 3), "merged_GBps": round(out_gb / dt, 3), "input_GB": round(in_gb, 2),
+               "stages": st}
+        # what the PCIe link allows: every input byte crosses it once, every output byte once, at the H2D rate
+        # measured on the copy stream in this run (the two directions are separate lanes: max, not sum)
+        h2d = st.get("h2d", {}).get("GBps")
+        if h2d:
+            rec["pcie_bound_merged_GBps"] = round(out_gb / (max(in_gb, out_gb) / h2d), 3)
+            rec["fraction_of_pcie_bound"] = round(rec["merged_GBps"] / rec["pcie_bound_merged_GBps"], 3)
+        print(json.dumps(rec))
     if not args.keep:
         shutil.rmtree(root)
 
