@@ -29,7 +29,11 @@ async def run_merge(config: MergeConfig, device: str, clean_cache: bool, **kwarg
     index_manager = LocalModelIndex(storage_path=config.storage_path, cache_path=config.cache_path)
     from . import distributed
     import os
-    if distributed.world_size() > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1":
+    # SHARDMERGE_INPLACE=1: a single process takes the multi-GPU path's in-place output shards too (pre-sized files,
+    # every tensor pwritten at its offset as soon as its copy to the host is done) instead of writing a shard when it
+    # is complete - one file takes ~7 GB/s on tmpfs whatever the thread count, so the sooner its writes start the better
+    # (tools/cli_bench.py: 5.1 against 3.9 GB/s of merged weights on the Llama-3-70B slice)
+    if distributed.world_size() > 1 or os.environ.get("SHARDMERGE_FORCE_DIST") == "1" or os.environ.get("SHARDMERGE_INPLACE") == "1":
         await distributed.run_partitioned_merge(config, index_manager, device)
         return
     from .merge import operator_class

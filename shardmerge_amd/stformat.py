@@ -57,6 +57,33 @@ def pwrite_tensors(fd: int, data_start: int, offsets: Dict[str, Tuple[int, int]]
     return total
 
 
+def mmap_write_tensors(fd: int, data_start: int, total: int, offsets: Dict[str, Tuple[int, int]],
+                       tensors: Dict[str, torch.Tensor], pool: ThreadPoolExecutor) -> int:
+    """The same through a shared mapping of the (pre-sized) file: writes to ONE file serialise on its inode lock
+    (measured on tmpfs: 8 threads of pwrite 4.8 GB/s), page faults of a mapping do not - numpy's copy releases the GIL."""
+    import mmap
+
+    import numpy as np
+    mm = mmap.mmap(fd, data_start + total, access=mmap.ACCESS_WRITE)
+    try:
+        dst = np.frombuffer(mm, dtype=np.uint8)
+        jobs, done = [], 0
+        for name, t in tensors.items():
+            src = t.reshape(-1).view(torch.uint8).numpy()
+            begin, end = offsets[name]
+            assert end - begin == src.size, (name, end - begin, src.size)
+            done += src.size
+            for off in range(0, src.size, _CHUNK):
+                n = min(_CHUNK, src.size - off)
+                jobs.append(pool.submit(np.copyto, dst[data_start + begin + off:data_start + begin + off + n], src[off:off + n]))
+        for j in jobs:
+            j.result()
+        del dst
+    finally:
+        mm.close()
+    return done
+
+
 def _pwrite_all(fd: int, view, pos: int):
     done = 0
     while done < len(view):

@@ -85,7 +85,7 @@ class ModelWriter:
         self._rank = {name: i for i, name in enumerate(self.layer_order)}
         self._pending: Dict[str, Dict[str, tuple]] = {}
         self._lock = threading.Lock()
-        self._jobs: "queue.Queue" = queue.Queue(maxsize=2)      # at most two shards waiting to be written
+        self._jobs: "queue.Queue" = queue.Queue(maxsize=4)      # at most four shards waiting to be written
         self._thread = None
         self._worker_error = None
         self._check_existing_shards()
@@ -156,10 +156,12 @@ class ModelWriter:
                 # offsets, several pieces at a time: save_file() serialises through one more copy on one thread
                 head, offsets = stformat.shard_header([(k, stformat.ST_NAMES[t.dtype], list(t.shape)) for k, t in ordered.items()],
                                                       {"format": "pt"})
-                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                fd = os.open(tmp, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
                 try:
                     os.pwrite(fd, head, 0)
                     os.ftruncate(fd, len(head) + nbytes)
+                    # (pwrite in pieces: 2x a shared mapping's page faults on tmpfs; writes to ONE file still serialise
+                    #  on its inode - 4.8 GB/s on the MI355X box - which is why several shards are written at a time)
                     stformat.pwrite_tensors(fd, len(head), offsets, ordered, self._io_pool())
                 finally:
                     os.close(fd)
@@ -182,6 +184,7 @@ class ModelWriter:
         while True:
             job = self._jobs.get()
             if job is None:
+                self._jobs.task_done()
                 return
             try:
                 self._write_shard(*job)
@@ -197,8 +200,12 @@ class ModelWriter:
             if not fresh:
                 continue
             if self._thread is None:
-                self._thread = threading.Thread(target=self._worker, name="shardmerge-writer", daemon=True)
-                self._thread.start()
+                # several shards in flight: one file's writes serialise in the kernel (its inode lock; tmpfs: page
+                # allocation), different files' do not
+                n = max(1, int(os.environ.get("SHARDMERGE_SHARD_WRITERS", "3")))
+                self._thread = [threading.Thread(target=self._worker, name=f"shardmerge-writer-{i}", daemon=True) for i in range(n)]
+                for th in self._thread:
+                    th.start()
             self._jobs.put((name, fresh))
         if wait or shard_name is None:
             self._jobs.join()
@@ -212,8 +219,10 @@ class ModelWriter:
     def finalize(self):
         self.flush()
         if self._thread is not None:
-            self._jobs.put(None)
-            self._thread.join()
+            for _ in self._thread:
+                self._jobs.put(None)
+            for th in self._thread:
+                th.join()
             self._thread = None
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)

@@ -104,6 +104,9 @@ def main():
     from shardmerge_amd.config import MergeConfig
     from shardmerge_amd import iostats
     for prefetch in args.runs.split(","):
+        inplace = prefetch.endswith("i")              # "1i": prefetch on + in-place output shards (SHARDMERGE_INPLACE)
+        prefetch = prefetch.rstrip("i")
+        os.environ["SHARDMERGE_INPLACE"] = "1" if inplace else "0"
         os.environ["SHARDMERGE_PREFETCH"] = prefetch
         out_dir = root / "merged"
         if out_dir.exists():
@@ -119,7 +122,7 @@ def main():
         dt = time.time() - t0
         st = iostats.snapshot(reset=True)
         in_gb, out_gb = 2.0 * n_params * (args.k + 1) / 1e9, 2.0 * n_params / 1e9
-        rec = {"cli_merge": "end to end", "model": args.model, "prefetch": prefetch == "1", "blocks": args.blocks, "k": args.k,
+        rec = {"cli_merge": "end to end", "model": args.model, "prefetch": prefetch == "1", "inplace_shards": inplace, "blocks": args.blocks, "k": args.k,
                "params": n_params, "seconds": round(dt, 3), "merged_GBps": round(out_gb / dt, 3), "input_GB": round(in_gb, 2),
                "stages": st}
         # what the PCIe link allows: every input byte crosses it once, every output byte once, at the H2D rate
