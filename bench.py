@@ -101,10 +101,19 @@ REF_NORM_BYTES_PER_DELTA = 4.0 + 0.25
 REF_NORM_BYTES_PER_PAIR = 0.5
 
 
-def moved_bytes_per_elem(k: int, norm_mode: str) -> float:
+def norms_fused_in_row_pass(rows: int, cols: int) -> bool:
+    """reference_cpu, round 4: the forward row pass k_f1 summarises its own deltas (no separate pass over finetunes and
+    bases) when its row plan can - whole groups of 2048 elements per row, at least two chunks of 65536 - and the shape
+    does not take the folded row pass k_f1q (14336 / 16384 / 28672 rows over <= 8192 columns), which keeps the
+    separate summary pass (sm_pipeline.hpp: fusable_rows, fold_shape)."""
+    folded = rows in (14336, 16384, 28672) and cols <= 8192
+    return rows > 1 and cols % 2048 == 0 and rows * cols >= 2 * 65536 and not folded
+
+
+def moved_bytes_per_elem(k: int, norm_mode: str, shape=None) -> float:
     """HBM bytes per tensor element this implementation moves for one K-way layer: 56n for
     a raw pair (K = 2), 85n at K = 3 (every delta's rows alone, intermediates stay spectral), plus the norm
-    emulation's passes in reference_cpu mode."""
+    emulation's passes in reference_cpu mode (shape: a tensor whose row pass carries the summaries has no such pass)."""
     if k <= 1:
         return 8.0
     if k == 2:
@@ -115,9 +124,18 @@ def moved_bytes_per_elem(k: int, norm_mode: str) -> float:
         #  read from HBM once: K (2 + 4) + 2 instead of 8 K; PMC: profiles/traffic_latest.json)
         base = (k * 6 + 2) + k * 7 + pairs * (4 + 6 + 2) + (pairs - 1) * 4 + 16
     if norm_mode == "reference_cpu":
-        # (the summary pass reads the shared base once per chunk as well: 2 K + 2 instead of 4 K)
-        base += (k * (REF_NORM_BYTES_PER_DELTA - 2.0) + 2.0) + (k - 1) * REF_NORM_BYTES_PER_PAIR
+        if shape is not None and norms_fused_in_row_pass(*shape):
+            base += k * 0.25 + (k - 1) * REF_NORM_BYTES_PER_PAIR          # the sampled prefix estimate only
+        else:
+            # (the summary pass reads the shared base once per chunk as well: 2 K + 2 instead of 4 K)
+            base += (k * (REF_NORM_BYTES_PER_DELTA - 2.0) + 2.0) + (k - 1) * REF_NORM_BYTES_PER_PAIR
     return float(base)
+
+
+def moved_bytes_of(shapes, k: int, norm_mode: str) -> float:
+    """element-weighted mean of moved_bytes_per_elem over a tensor list"""
+    tot = sum(r * c for r, c in shapes)
+    return sum(moved_bytes_per_elem(k, norm_mode, (r, c)) * r * c for r, c in shapes) / max(tot, 1)
 
 
 def csrc_stamp() -> str:
@@ -263,6 +281,87 @@ def load_traffic(workload: str, k: int, kernel: str):
     return data.get(kernel, {}).get("hbm_bytes_per_launch")
 
 
+def product_path_bench(args, world, rank, device, dist):
+    """--product-path: the PRODUCT's multi-GPU loop (distributed.py: plan, base-shard broadcasts a window ahead,
+    prefetching loader, in-place output shards), timed end to end on a synthetic on-disk model - what `python -m shard
+    merge` does under torchrun.  Strong scaling: ONE model of --blocks Llama-3-70B blocks (default 2 per rank), K
+    finetunes, partitioned over the N ranks.  Reports merged GB/s (output bytes / max-over-ranks wall time) and, per
+    rank, the share of its loop spent waiting for a base shard's payload."""
+    import asyncio
+    import shutil
+    sys.path.insert(0, str(REPO / "tools"))
+    import cli_bench
+    from shardmerge_amd import distributed as sd
+    from shardmerge_amd.config import MergeConfig
+    from shardmerge_amd.index import LocalModelIndex
+    k = args.k
+    blocks = args.blocks or 2 * world
+    root = Path(args.product_root)
+    os.environ["LOCAL_RANK"] = str(device.index)        # (a one-GPU rehearsal over gloo puts every rank on the same card)
+    model = "llama3-8b" if args.workload == "llama3-8b" else "llama3-70b"
+    if rank == 0:
+        if root.exists():
+            shutil.rmtree(root)
+        root.mkdir(parents=True)
+        cfg_path, n_params = cli_bench.write_models(root, blocks, k, str(device), model)
+    if dist:
+        dist.barrier()
+    cfg_path = root / "merge.yaml"
+
+    def one_run():
+        if rank == 0 and (root / "merged").exists():
+            shutil.rmtree(root / "merged")
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        cfg = MergeConfig.from_yaml(cfg_path)
+        t0 = time.time()
+        st = asyncio.run(sd.run_partitioned_merge(cfg, LocalModelIndex(cfg.storage_path), str(device)))
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        return time.time() - t0, st
+
+    for _ in range(max(args.warmup, 1)):
+        one_run()
+    times, stats = [], None
+    for _ in range(args.steps):
+        dt, stats = one_run()
+        times.append(dt)
+    dt = sum(times)
+    per_rank = [stats]
+    if dist:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, stats)
+    if rank == 0:
+        out_bytes = sum(s_["out_bytes"] for s_ in per_rank)
+        total_out = 0
+        for f in (root / "merged").glob("*.safetensors"):
+            total_out += f.stat().st_size
+        result = {
+            "metric": "merged-weight GB/s per GPU + % HBM roofline, Llama-3-70B 3-way FFT merge",
+            "mode": "product_path (distributed.run_partitioned_merge end to end: disk -> H2D -> merge -> D2H -> disk)",
+            "value": total_out * args.steps / dt / 1e9, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": f"synthetic safetensors under {root}", "norm_mode": "reference_cpu",
+            "config": {"workload": f"{model} block tensors x {blocks} blocks (+ embedding, norm, lm_head), K={k}, one model partitioned over {world} rank(s)",
+                       "k": k, "parallelism": f"tensor-partition x{world}: one broadcast per base shard, no reduction"},
+            "output_GB": round(total_out / 1e9, 3), "input_GB": round(total_out * (k + 1) / 1e9, 3),
+            "per_rank": [{"rank": s_["rank"], "tensors": s_["tensors"], "out_GB": round(s_["out_bytes"] / 1e9, 3),
+                          "loop_s": round(s_["loop_s"], 3), "wait_base_pct": round(100.0 * s_["wait_base_s"] / max(s_["loop_s"], 1e-9), 1),
+                          "merge_pct": round(100.0 * s_["merge_s"] / max(s_["loop_s"], 1e-9), 1)} for s_ in per_rank],
+        }
+        print(json.dumps(result))
+        if not os.environ.get("SHARDMERGE_BENCH_KEEP"):
+            shutil.rmtree(root, ignore_errors=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +379,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra timed steps in the other norm mode")
+    ap.add_argument("--product-path", action="store_true",
+                    help="measure shardmerge_amd.distributed.run_partitioned_merge end to end instead of resident tensors: "
+                         "synthetic safetensors models under --product-root, N ranks partition ONE model (strong scaling), "
+                         "base shards travel by broadcast, every rank writes its results into the output shards")
+    ap.add_argument("--product-root", default="/dev/shm/smbench_product")
     args = ap.parse_args()
     from shardmerge_amd.constants import tune_hip_queues
     tune_hip_queues()                   # 8 engines + their side streams: before the first GPU call (children inherit it)
@@ -306,6 +410,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+
+    if args.product_path:
+        return product_path_bench(args, world, rank, device, dist)
 
     from shardmerge_amd.engine import Engine, get_engine
     engine = get_engine(device)
@@ -384,8 +491,8 @@ def main():
         # over the HBM peak: an effective, speedup-style figure ...
         "pipeline_hbm_frac": alg_bytes_per_elem(k) * n_elems * args.steps / dt / HBM_PEAK,
         # ... and the bytes this implementation actually moves (it keeps intermediates spectral, fuses the norms)
-        "pipeline_hbm_frac_moved": moved_bytes_per_elem(k, args.norm_mode) * n_elems * args.steps / dt / HBM_PEAK,
-        "pipeline_bytes_per_elem": {"canonical": alg_bytes_per_elem(k), "moved": moved_bytes_per_elem(k, args.norm_mode)},
+        "pipeline_hbm_frac_moved": moved_bytes_of(shapes, k, args.norm_mode) * n_elems * args.steps / dt / HBM_PEAK,
+        "pipeline_bytes_per_elem": {"canonical": alg_bytes_per_elem(k), "moved": round(moved_bytes_of(shapes, k, args.norm_mode), 3)},
         "spectral_intermediates": not any(item.startswith("spectral_intermediates=0") for item in os.environ.get("SMHIP_DEBUG", "").split(",")),
         "base_broadcast_ms": bcast_ms,
     }

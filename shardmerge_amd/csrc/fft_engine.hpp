@@ -524,10 +524,15 @@ template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::i
 #ifndef SM_DIAG_NOFFT
 #define SM_DIAG_NOFFT 0
 #endif
+struct FloatPairRef { float& a; float& b; };      // what a lane_pair_trade getter returns
 struct NoHook { template <class C> SM_HD void operator()(C) const {} };
 // after_nat(comp_c): called once per component between the barrier behind the natural scatter and the next one - LDS
 // holds the natural-order values of that component and may be READ (a work-group level hook: it may run collectives)
-template <class P, bool PACK = true, int DIAG = 0, class Ex, class StT, class NatScatter, class FinGather, class AfterNat = NoHook>
+// SKIPS (static plans): bit 0 - the caller has put the values in FIRST-PASS layout already (x[m*R0 + i] = in[j + i*N/R0],
+// j = t + m*T < N/R0): no natural scatter / first gather, nat_scatter is never called; bit 1 - the caller takes the
+// result in LAST-PASS layout (x[m*RL + i] = out[j + i*N/RL], j = t + m*T < N/RL): no final scatter / gather, fin_gather
+// is never called.  Each saves one of the transform's exchanges through LDS (two barriers and 2 x N dwords per component).
+template <class P, bool PACK = true, int DIAG = 0, int SKIPS = 0, class Ex, class StT, class NatScatter, class FinGather, class AfterNat = NoHook>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather, AfterNat after_nat = AfterNat{}) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);
@@ -542,7 +547,9 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
         (void)N; (void)T; (void)LF;
         return;
     }
+    static_assert(SKIPS == 0 || P::is_static, "layout skips need a static plan");
     if constexpr (P::is_static) {
+        if constexpr (!(SKIPS & 1))
         static_for<0, 2>([&](auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             ex.each(st, [&](int tid, S& s) { nat_scatter(tid, s, comp_c); });
@@ -563,6 +570,7 @@ SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter 
             constexpr int Ns = P::ns(p);
             constexpr bool last = (p + 1 == P::npass);
             ex.each(st, [&](int tid, S& s) { pass_compute<r, PACK>(s.xr, s.xi, N, Ns, T, tid % T, pl.tw); });
+            if constexpr (!(last && (SKIPS & 2)))
             static_for<0, 2>([&](auto comp_c) {
                 constexpr int comp = decltype(comp_c)::value;
                 ex.each(st, [&](int tid, S& s) {

@@ -1066,6 +1066,30 @@ template <class P> constexpr int f2s_groups() {
                             // MI355X it takes 4-12 % off f2s and puts 8-12 % on the row pass (half-line stores) - net loss
 #endif
 constexpr int F2S_ILV = SM_F2S_ILV;
+// DIRECT (round 4): the column pass takes its loads straight into the first radix pass's layout and stores straight out
+// of the last one's - two of the transform's four exchanges through LDS (and 8 of its 16 barriers) go away:
+//  * first pass, butterfly j = t + m T takes rows j + i N/R0: lanes 2k and 2k + 1 need the SAME row pairs (T1 holds rows
+//    2m, 2m + 1 in one float4) - the even lane loads the pairs of even i, the odd lane those of odd i, and they trade
+//    halves through a quad-permute DPP move (Ex::lane_pair_trade), no LDS;
+//  * last pass, thread t holds outputs t + T u: 64 lanes store 256 contiguous bytes per instruction (dword stores;
+//    measured with tools/membench2.hip: as fast as the exchanged 16-byte form at two columns per work-group).
+// Columns are dealt by thread group (g = tid / T) instead of by lane (tid % G): the loader must be the owner.
+// MEASURED ON MI355X AND LEFT OFF (profiles/r04_ab_f2s_direct.txt): bit-identical results, but the owner-loads mapping
+// gives up the 32-byte pieces two adjacent lanes read (f2s 529 -> 583 us at 28672 x 8192, 464 -> 567 at 8192 x 28672)
+// and the dword stores lose more than the exchange they save on the 8192-point plan (464 -> 531; 529 -> 516 on the
+// folded 7168-point one): the column passes are bound by their access pattern, not by their exchanges.
+#ifndef SM_F2S_DIRECT
+#define SM_F2S_DIRECT 0     // bit 0: loads into the first pass's layout (DPP trade), bit 1: stores out of the last pass's
+#endif
+template <class P, int G> constexpr int f2s_direct() {
+    if constexpr (!P::is_static) return 0;
+    else {
+        constexpr int R0 = P::radix(0);
+        constexpr bool ok = F2S_ILV == 1 && (G == 1 || G == 2) && P::npass >= 2 && P::T % 2 == 0 && R0 % 2 == 0 &&
+                            (P::N / R0) % 2 == 0 && (EMAX / R0) * R0 * P::T >= P::N;
+        return ok ? (SM_F2S_DIRECT & 3) : 0;
+    }
+}
 template <class P, int G, bool FOLD = false, class Ex>
 SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     if constexpr (FOLD && !fold_col_plan<P>()) { return; } else {
@@ -1094,6 +1118,43 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
     const int half = R / 2;
     uint32_t* lhist = (uint32_t*)(lds + G * LF);
 
+    constexpr int DIRECT = f2s_direct<P, G>();
+    if constexpr ((DIRECT & 1) != 0) {
+        constexpr int R0 = P::radix(0), MB0 = EMAX / R0, nb0 = P::N / R0;
+        ex.each(st, [&](int tid, FftState& s) {
+            const int g = tid / T, t = tid % T;
+            const int k2 = kbase + g;
+            const int kc = k2 < p.Cb ? k2 : p.Cb - 1;
+            const int par = t & 1;
+            // (clamped address, masked value: a load behind a branch is waited for on the spot)
+            static_for<0, MB0>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                const bool live = (t + m * T) < nb0 && k2 < p.Cb;
+                static_for<0, R0 / 2>([&](auto q_c) {
+                    constexpr int q = decltype(q_c)::value;
+                    // the row pair of rows j + i nb0, j = t + m T, i = 2 q + par (nb0, T even)
+                    const int pm = live ? (t >> 1) + m * (T / 2) + q * nb0 + par * (nb0 / 2) : 0;
+                    cf4 v;
+#if defined(SM_DIAG_NOMEM)
+                    v = cf4{(float)q, (float)t, 1.f, (float)kc};
+#else
+                    if constexpr (FOLD) v = t1[(size_t)(kc / p.slab) * p.slab_elems + (size_t)pm * p.slab + (kc % p.slab)];
+                    else v = t1[(size_t)pm * p.pitch4 + kc];
+#endif
+                    s.xr[m * R0 + 2 * q] = live ? v.x : 0.f; s.xi[m * R0 + 2 * q] = live ? v.y : 0.f;
+                    s.xr[m * R0 + 2 * q + 1] = live ? v.z : 0.f; s.xi[m * R0 + 2 * q + 1] = live ? v.w : 0.f;
+                });
+            });
+            if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
+        });
+        // the even lane holds (own rows of i = 2q | the partner's rows of i = 2q), the odd lane the mirror image
+        ex.template lane_pair_trade<MB0 * (R0 / 2) * 2>(st, [](FftState& s, auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            constexpr int idx = k / 2, m = idx / (R0 / 2), q = idx % (R0 / 2);
+            float* arr = (k % 2) ? s.xi : s.xr;
+            return FloatPairRef{arr[m * R0 + 2 * q], arr[m * R0 + 2 * q + 1]};
+        });
+    } else
     ex.each(st, [&](int tid, FftState& s) {
         const int b = tid % G, lane = tid / G;
         const int k2 = kbase + b;
@@ -1119,7 +1180,7 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
-    wg_fft<P, true, 4>(ex, st, pl, lds,
+    wg_fft<P, true, 4, DIRECT>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
@@ -1159,6 +1220,33 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         float* dre = re_ + pl_off + poff;
         float* dim = p.im + pl_off + poff;
         float imsq = 0.f;
+        if constexpr ((DIRECT & 2) != 0) {
+            // last-pass layout: slot m RL + i is output j + i NsL, j = t + m T: consecutive lanes, consecutive floats
+            constexpr int RL = P::radix(P::npass - 1), MBL = EMAX / RL, NsL = P::N / RL;
+            static_for<0, MBL>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                const int j = t + m * T;
+                if (j < NsL) {
+                    static_for<0, RL>([&](auto i_c) {
+                        constexpr int i = decltype(i_c)::value, e = m * RL + i;
+                        const float vr = s.xr[e] * sc;
+#if defined(SM_DIAG_NOMEM)
+                        if (vr == 12345.678f)
+#endif
+                        dre[j + i * NsL] = vr;
+                        if (role_a_) {
+                            const float vi = s.xi[e] * sc;
+#if defined(SM_DIAG_NOMEM)
+                            if (vi == 12345.678f)
+#endif
+                            dim[j + i * NsL] = vi;
+                            imsq += vi * vi;
+                        }
+                        if (p.hist) ex.lds_atomic_add(&lhist[(f2u(vr) & 0x7fffffffu) >> 20], w);
+                    });
+                }
+            });
+        } else
 #pragma unroll
         for (int u = 0; u < EMAX / 4; ++u) {
             const int k0 = 4 * (t + u * T);
@@ -3581,8 +3669,12 @@ SM_HD uint32_t wg_select_lds(Ex& ex, StT& st, uint32_t* hist, uint32_t* part, ui
     return prefix;
 }
 
+template <class P> constexpr bool pair1d_plan() {      // 1-D tensors go through this kernel up to PAIR1D_MAX_C elements only
+    if constexpr (P::is_static) return P::N <= PAIR1D_MAX_C; else return true;
+}
 template <class P, class Ex>
 SM_HD void k_pair1d(Ex& ex, const Pair1dParams& p) {
+    if constexpr (!pair1d_plan<P>()) { return; } else {      // (the 16384- / 28672-point bodies were dead code with 594 spilled registers)
     typename Ex::template State<FftState> st;
     ex.init(st);
     const FftPlanDev& pl = p.plan;
@@ -3760,6 +3852,7 @@ SM_HD void k_pair1d(Ex& ex, const Pair1dParams& p) {
     if (p.fin.norm_partials) {
         ex.sync();
         ex.template block_sum<2>(st, [&](const double* tot) { p.fin.norm_partials[0] = tot[0]; p.fin.norm_partials[1] = 0.0; });
+    }
     }
 }
 

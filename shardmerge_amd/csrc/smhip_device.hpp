@@ -34,6 +34,20 @@ struct DeviceExec {
 #pragma unroll
         for (int i = 0; i < N; ++i) b[i] = (uint32_t)__shfl_down((int)a[i], DELTA, 64);
     }
+    // Lanes t and t ^ 1 trade one float each, NP times: of the pair (a, b) that get(s, k) names, the even lane gives
+    // its b and takes the partner's a into it, the odd lane gives its a and takes the partner's b into it (one select,
+    // one quad-permute DPP move, two selects; no LDS).  get(S&, integral_constant<int, k>) -> {float& a, float& b}.
+    template <int NP, class S, class Get>
+    __device__ __forceinline__ void lane_pair_trade(State<S>& st, Get get) {
+        const bool odd = (threadIdx.x & 1u) != 0;
+        static_for<0, NP>([&](auto k_c) {
+            auto pr = get(st.s, k_c);
+            const float give = odd ? pr.a : pr.b;
+            const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            pr.a = odd ? got : pr.a;
+            pr.b = odd ? pr.b : got;
+        });
+    }
     // sum NV doubles (State::red) over the work-group; f(total) runs on thread 0.
     // Uses the first LDS_SCRATCH_FLOATS of LDS; ends with a barrier.
     template <int NV, class S, class F>

@@ -581,6 +581,10 @@ async def run_partitioned_merge(config: MergeConfig, index: LocalModelIndex, dev
             fh.write(merger.get_readme())
     if dist is not None:
         dist.barrier()
+    # what this rank did (bench.py --product-path gathers these): tensors and output bytes it owned, the wall time
+    # of its loop, how much of it it spent waiting for a base shard's broadcast and how much inside merges
+    return {"rank": me, "tensors": len(mine), "out_bytes": sum(int(metas[s_][n_][2]) for (s_, n_) in mine if n_ in metas[s_]),
+            "loop_s": busy, "wait_base_s": t_wait, "merge_s": t_merge, "shards": len(todo)}
 
 
 async def _merge_block_tensor(merger: FourierMerge, engine, sl: ShardLayer, base_view: torch.Tensor) -> torch.Tensor:

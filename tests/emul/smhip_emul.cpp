@@ -46,6 +46,16 @@ struct HostExec {
             for (int i = 0; i < N; ++i) b[i] = a[i];
         }
     }
+    template <int NP, class S, class Get> void lane_pair_trade(State<S>& st, Get get) {
+        for (int t = 0; t + 1 < nt_; t += 2) {                      // even lane t, odd lane t + 1
+            static_for<0, NP>([&](auto k_c) {
+                auto ev = get(st.v[t], k_c);
+                auto od = get(st.v[t + 1], k_c);
+                const float give_e = ev.b, give_o = od.a;
+                ev.b = give_o; od.a = give_e;
+            });
+        }
+    }
     template <int NV, class S, class F> void block_sum(State<S>& st, F&& f) {
         double tot[NV];
         for (int q = 0; q < NV; ++q) tot[q] = 0;

@@ -681,6 +681,29 @@ def test_folded_column_pass_is_taken_for_the_mlp_shapes(engine):
         assert pc.spectral_residual(d1.cpu(), d0.cpu(), drop=64)[1] < res_bar, mode
 
 
+def test_bench_product_path_rehearsal_two_ranks_on_one_card(tmp_path):
+    """bench.py --gpus 2 --product-path: the multi-GPU PRODUCT loop (plan, base-shard broadcasts a window ahead,
+    prefetching loader, in-place output shards) measured end to end - rehearsed here with 2 gloo ranks sharing the
+    box's one GPU, so that the first 8-GPU run over RCCL measures distributed.py and not a list of resident tensors."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, SHARDMERGE_BENCH_BACKEND="gloo", SHARDMERGE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--product-path", "--workload", "llama3-8b", "--blocks", "2",
+                          "--k", "2", "--steps", "1", "--warmup", "1", "--product-root", str(tmp_path / "model")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert len(rec["per_rank"]) == 2 and all(r["tensors"] > 0 for r in rec["per_rank"])
+    assert sum(r["tensors"] for r in rec["per_rank"]) == 2 * 9 + 3
+    print(line)
+
+
 def test_partitioned_merge_through_rccl_world_size_1(tmp_path, golden):
     """The multi-GPU product path (shardmerge_amd/distributed.py) with its collectives REAL: one
     rank, backend nccl (= RCCL), process group initialised on the device, the base-shard
