@@ -218,6 +218,45 @@ def gen_floor(manifest):
     manifest["floor_meta"] = meta
 
 
+def run_ref_legacy_layer(case, tmp):
+    """The reference's LEGACY operator (shard/merge/fourier.py:35-205) on a layer, tensor loads faked as for the fast
+    one.  It subtracts the base from the finetunes IN PLACE (fourier.py:113): every load hands out a clone."""
+    from shard.merge.fourier import FourierMerge as LegacyFourierMerge
+    tensors, models, cfg_kw, layer_name = gi.layer_inputs(case)
+    cfg = MergeConfig(finetune_merge=[MergeModel(**m) for m in models], output_base_model=cfg_kw["output_base_model"],
+                      output_dir=str(Path(tmp) / "out"), device="cpu", cache_dir=str(Path(tmp) / f"cache_{case['id']}"),
+                      storage_dir=str(Path(tmp) / "storage"))
+    idx = HFMultiModelIndex(download_manager=DownloadManager(storage_path=Path(tmp) / "storage"), cache_path=Path(tmp) / "cache_idx")
+    merger = LegacyFourierMerge(config=cfg, task_add_models=case.get("task_add"), index_manager=idx)
+
+    def fake_get(model_uri, tensor_name, device="cpu"):
+        p = AsyncMock()
+        p.get = AsyncMock(return_value=tensors[model_uri].clone())
+        return p
+    sl = ShardLayer(layer_order_idx=1, shard_name="model-00001.safetensors", layer_name=layer_name, written=False)
+
+    async def go():
+        with patch.object(idx, "get_tensor", side_effect=fake_get):
+            return await merger._merge_layer(sl, device="cpu")
+    return asyncio.run(go())
+
+
+def gen_legacy(manifest):
+    """G12: outputs of the legacy operator, and its self-distance under fp64 FFTs (the K >= 3 floor, as for G7)."""
+    store, floors = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for case in gi.LEGACY_CASES:
+            out = run_ref_legacy_layer(case, tmp)
+            with fp64_fft():
+                out64 = run_ref_legacy_layer(case, tmp)
+            store[case["id"]] = out.float().contiguous().clone()
+            floors[case["id"]] = float((out.double() - out64.double()).norm() / out.double().norm())
+            manifest["inputs"][case["id"]] = sum((gi.checksum(v) for v in gi.layer_inputs(case)[0].values()), [])
+            print(case["id"], out.dtype, floors[case["id"]])
+    save_file(store, str(OUT / "g12_legacy.safetensors"))
+    manifest["legacy_self_floor"] = floors
+
+
 def gen_cli(manifest):
     """G8: the reference CLI end to end on a tiny local model."""
     from click.testing import CliRunner
@@ -296,6 +335,12 @@ def main():
         with open(OUT / "manifest.json", "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
+    if "--only-legacy" in sys.argv:              # add G12 without touching the other fixtures
+        manifest = json.load(open(OUT / "manifest.json"))
+        gen_legacy(manifest)
+        with open(OUT / "manifest.json", "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if "--only-floor" in sys.argv:               # add G11 without touching the other fixtures
         manifest = json.load(open(OUT / "manifest.json"))
         gen_floor(manifest)
@@ -319,6 +364,7 @@ def main():
     gen_addition(manifest)
     gen_corr(manifest)
     gen_floor(manifest)
+    gen_legacy(manifest)
     with open(OUT / "manifest.json", "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     total = sum(p.stat().st_size for p in OUT.glob("*.safetensors"))

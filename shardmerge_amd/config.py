@@ -38,7 +38,7 @@ _REQUIRED = ("output_base_model", "finetune_merge", "output_dir")
 MERGE_OPTION_DEFAULTS = {"cutoff_pct": 0.08, "cull_start_pct": 0.20, "t_sum": 1.0, "target_norm_offset": 1e-10, "b": 0.1}
 MERGE_OPTION_RANGES = {"cutoff_pct": (0.0, 1.0), "cull_start_pct": (0.0, 1.0), "t_sum": (-1e6, 1e6), "target_norm_offset": (0.0, 1e6),
                        "b": (0.0, 1e6)}
-OPERATORS = ("fourier", "addition", "task_addition")
+OPERATORS = ("fourier", "addition", "task_addition", "fourier_legacy")
 
 
 @dataclass
@@ -72,6 +72,7 @@ class MergeConfig:
     merge_options: Dict[str, float] = field(default_factory=dict)
     operator: str = "fourier"
     norm_mode: str = DEFAULT_NORM_MODE
+    task_add_models: List[str] = field(default_factory=list)      # operator fourier_legacy only (reference fourier.py:39,115)
 
     # -- derived views ------------------------------------------------------------
     def _first(self, flag: str) -> Optional[MergeModel]:
@@ -136,6 +137,10 @@ class MergeConfig:
         if norm_mode not in NORM_MODES:
             raise click.BadParameter("merge_options.norm_mode must be 'exact' or 'reference_cpu'")
         raw["norm_mode"] = norm_mode
+        task_add = opts.pop("task_add_models", [])
+        if not isinstance(task_add, list) or not all(isinstance(x, str) for x in task_add):
+            raise click.BadParameter("merge_options.task_add_models must be a list of model names")
+        raw["task_add_models"] = task_add
         operator = opts.pop("operator", "fourier")
         if operator not in OPERATORS:
             raise click.BadParameter(f"merge_options.operator must be one of {list(OPERATORS)}")

@@ -12,4 +12,7 @@ def operator_class(name: str = "fourier"):
     if name == "task_addition":
         from .taskaddition import TaskAdditionMerge
         return TaskAdditionMerge
+    if name == "fourier_legacy":
+        from .fourier_legacy import LegacyFourierMerge
+        return LegacyFourierMerge
     raise ValueError(f"unknown merge operator {name!r}")

@@ -142,6 +142,17 @@ FLOOR_CASES = [
 FLOOR_DELTA_SCALE = 256.0          # merged deltas (~3e-3) are stored as fp16(delta * 256): 2.8e-4 relative rounding
 
 
+# G12: the reference's legacy in-RAM FourierMerge (shard/merge/fourier.py; inputs as layer_inputs): K = 2, K = 3
+# (cosine pairing, median target norm), a task_add_models post-pass, the Arithmetic-FFT branch
+LEGACY_CASES = [
+    {"id": "legacy_k2", "shape": (256, 256), "seed": 610, "k": 2},
+    {"id": "legacy_k3", "shape": (256, 256), "seed": 620, "k": 3},
+    {"id": "legacy_k3_taskadd", "shape": (256, 128), "seed": 630, "k": 3, "task_add": ["org/ft2"]},
+    {"id": "legacy_k2_arith", "shape": (128, 128), "seed": 640, "k": 2, "sig": (0.003, 1e-5)},
+    {"id": "legacy_k4", "shape": (128, 256), "seed": 650, "k": 4},
+]
+
+
 # G9: AdditionMerge / TaskAdditionMerge - every tensor goes through the same path
 ADDITION_CASES = [
     {"id": "add_bf16_k2", "shape": (64, 96), "k": 2, "dtype": "bfloat16", "seed": 300},

@@ -364,3 +364,32 @@ def check_noise_seed_sensitivity(engine, golden, case):
     for o in outs[1:]:
         assert so.rel_err(o, fx["out"]) <= FLOOR_RATIO * floor_out
     return d01, d02, floor_out
+
+
+# ---- the reference's legacy in-RAM operator (shard/merge/fourier.py) ------------------------------------------------
+def check_legacy(engine, golden, case):
+    """`merge_options.operator: fourier_legacy` (shardmerge_amd/merge/fourier_legacy.py) against the outputs of the
+    reference's own class (G12, oracle/gen_golden.py --only-legacy): median target norm, cosine pairing, deltas and
+    first-round norms in the models' dtype, the task_add_models post-pass, fp32 result."""
+    import asyncio
+    from shardmerge_amd.config import MergeConfig, MergeModel
+    from shardmerge_amd.merge.fourier_legacy import LegacyFourierMerge
+    from shardmerge_amd.writer import ShardLayer
+    tensors, models, cfg_kw, lname = gi.layer_inputs(case)
+    cfg = MergeConfig(finetune_merge=[MergeModel(**m) for m in models], output_base_model=cfg_kw["output_base_model"], output_dir="unused")
+    op = LegacyFourierMerge(cfg, task_add_models=case.get("task_add"), engine=engine)
+    dev = engine.device
+
+    async def fetch(uri, name, device):
+        return tensors[uri].to(dev)
+    op._fetch = fetch
+    out = asyncio.run(op._merge_layer(ShardLayer(1, "s", lname, False), str(dev))).cpu()
+    ref = golden.get("g12_legacy.safetensors", case["id"])
+    assert out.dtype == torch.float32 and out.shape == ref.shape              # (fourier.py:205: no bf16 cast)
+    floor = golden.manifest["legacy_self_floor"][case["id"]]
+    total, resid = spectral_residual(out, ref)
+    if floor < 1e-3:                      # one slerp round (or none) decides nothing on rounding noise
+        assert resid < 2e-5 and total < 1e-3, (total, resid)
+    else:
+        assert total <= 2.5 * floor + 1e-4, (total, floor)
+    return total, resid, floor

@@ -1011,3 +1011,9 @@ def test_row_pass_summarises_its_deltas_for_the_norm_emulation(engine, k, shape,
         engine.ctx.debug_option("fuse_norms", 1)
         engine.ctx.debug_option("fold_min_rows", 0)
         engine.ctx.profile(False)
+
+
+@pytest.mark.parametrize("case", gi.LEGACY_CASES, ids=lambda c: c["id"])
+def test_legacy_fourier_operator(engine, golden, case):
+    """the reference's older FourierMerge class (shard/merge/fourier.py:35-205) behind the same boundary"""
+    print(pc.check_legacy(engine, golden, case))

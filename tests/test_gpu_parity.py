@@ -877,3 +877,9 @@ def test_one_launch_pair_merge_of_1d_tensors_on_device(engine, shape):
 
 def test_1d_policies_through_the_one_launch_kernel_on_device(engine):
     emul_tier.test_1d_policies_through_the_one_launch_kernel(engine)
+
+
+@pytest.mark.parametrize("case", gi.LEGACY_CASES, ids=lambda c: c["id"])
+def test_legacy_fourier_operator_on_device(engine, golden, case):
+    """the reference's older FourierMerge class (shard/merge/fourier.py:35-205) behind the same boundary"""
+    print(pc.check_legacy(engine, golden, case))

@@ -367,3 +367,26 @@ def test_cli_with_the_addition_operators(tmp_path, emul, op):
                 assert torch.equal(f.get_tensor(k), fn([models[1][k], models[2][k]], models[0][k]).to(torch.bfloat16)), k
                 n += 1
     assert n == sum(len(v) for v in gi.CLI_SHARDS.values())
+
+
+def test_legacy_operator_is_selectable_from_yaml(tmp_path):
+    """merge_options.operator: fourier_legacy (+ task_add_models) -> LegacyFourierMerge (reference shard/merge/fourier.py)"""
+    import yaml
+    from shardmerge_amd.config import MergeConfig
+    from shardmerge_amd.merge import operator_class
+    from shardmerge_amd.merge.fourier_legacy import LegacyFourierMerge
+    doc = {"output_base_model": "org/base", "output_dir": str(tmp_path / "o"),
+           "finetune_merge": [{"model": "org/a", "base": "org/base", "alpha": 0.5, "is_input": True, "is_output": True},
+                              {"model": "org/b", "base": "org/base", "alpha": 0.5}],
+           "merge_options": {"operator": "fourier_legacy", "task_add_models": ["org/b"]}}
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(doc))
+    cfg = MergeConfig.from_yaml(p)
+    assert cfg.operator == "fourier_legacy" and cfg.task_add_models == ["org/b"]
+    op = operator_class(cfg.operator)(config=cfg, index_manager=None)
+    assert isinstance(op, LegacyFourierMerge) and op.task_add_models == ["org/b"]
+    assert op.get_readme() == "# SLERP-FFT Merged Model\nBase: org/base\nModels merged:\n- org/a\n- org/b\n"
+    doc["merge_options"]["task_add_models"] = "org/b"
+    p.write_text(yaml.safe_dump(doc))
+    with pytest.raises(Exception):
+        MergeConfig.from_yaml(p)
