@@ -281,6 +281,38 @@ def load_traffic(workload: str, k: int, kernel: str):
     return data.get(kernel, {}).get("hbm_bytes_per_launch")
 
 
+def live_traffic(workload: str, k: int):
+    """HBM traffic per launch of every kernel, measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
+    they do not fit one pass) over one single-stream step of one block of the workload, as child processes (the program
+    itself behind `--`, cwd /tmp), corrected as MI355X_MICROARCH.md prescribes (tools/pmc_traffic.py).  Returns
+    ({kernel: record}, None) or (None, why not)."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if any(k_.startswith(("ROCPROF", "ROCP_")) for k_ in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    sys.path.insert(0, str(REPO / "tools"))
+    import pmc_traffic
+    child = [sys.executable, str(REPO / "bench.py"), "--workload", workload, "--k", str(k), "--blocks", "1", "--steps", "1", "--warmup", "0",
+             "--streams", "1", "--no-cpu-baseline", "--no-profile", "--no-alt-mode", "--prewarm-seconds", "0", "--no-live-traffic"]
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, ctr)
+                r = subprocess.run([prof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=300)
+                if r.returncode != 0:
+                    return None, f"rocprofv3 --pmc {ctr} exited {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+                got[ctr] = pmc_traffic.load(d, ctr)
+        return pmc_traffic.aggregate(got["FETCH_SIZE"], got["WRITE_SIZE"]), None
+    except Exception as exc:            # a profiler problem must not cost the bench line
+        return None, f"{type(exc).__name__}: {exc}"
+
+
 def product_path_bench(args, world, rank, device, dist):
     """--product-path: the PRODUCT's multi-GPU loop (distributed.py: plan, base-shard broadcasts a window ahead,
     prefetching loader, in-place output shards), timed end to end on a synthetic on-disk model - what `python -m shard
@@ -379,6 +411,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra timed steps in the other norm mode")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes for roofline.traffic (the committed profiles/traffic_latest.json is quoted when its stamp matches)")
     ap.add_argument("--product-path", action="store_true",
                     help="measure shardmerge_amd.distributed.run_partitioned_merge end to end instead of resident tensors: "
                          "synthetic safetensors models under --product-root, N ranks partition ONE model (strong scaling), "
@@ -541,9 +575,20 @@ def main():
         per_elem = kernel_alg_bytes_per_elem(dom, k)
         alg = per_elem * n_2d
         launches, dom_ms = table[dom]
-        traffic = load_traffic(args.workload, k, dom)
+        traffic, traffic_src = None, None
+        if world == 1 and not args.no_live_traffic:
+            live, why = live_traffic(args.workload, k)
+            if live is not None and dom in live:
+                traffic, traffic_src = live[dom]["hbm_bytes_per_launch"], "two rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE) in this run, one block, single stream"
+                result["traffic_by_kernel"] = {n_: round(v["hbm_bytes_per_launch"]) for n_, v in live.items() if not n_.startswith("_") and v["launches"]}
+            else:
+                traffic_src = f"live measurement unavailable ({why})"
+        if traffic is None:
+            traffic = load_traffic(args.workload, k, dom)
+            if traffic is not None:
+                traffic_src = "profiles/traffic_latest.json (stamped with this tree's kernel sources)"
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms / 1e3) / 1e9, "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": alg / (dom_ms / 1e3) / HBM_PEAK, "traffic": traffic,
+                              "unit": "GB/s", "frac": alg / (dom_ms / 1e3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                               "alg_bytes_per_launch": alg / launches, "avg_launch_ms": dom_ms / launches,
                               "alg_bytes_per_elem_per_layer": per_elem}
         # every streaming kernel's own fraction of the HBM peak (same measurement)

@@ -42,12 +42,13 @@ NAMES = {"KF1": "f1_rows_fwd", "KF2": "f2_cols_fwd", "KI1x1": "i1_cols_inv", "KI
          "KDftp": "dft_across_slices", "KDftpPairs": "dft_across_slices", "KTranspose": "transpose", "KPair1d": "pair_1d",
          "KSelect2": "select_lvl2", "KSelect2Cull": "select_lvl2_cull", "KBlendSel": "blend", "KSpecCheck": "select_spec_check", "KBlend": "blend", "KHist": "select_hist", "KReduce": "slerp_reduce", "KCombine": "combine",
          "KAtenPre": "aten_norm_pre", "KAtenPreC": "aten_norm_pre", "KAtenPart": "aten_norm_part", "KAtenPartC": "aten_norm_part",
+         "KAtenPart16": "aten_norm_part", "KAtenPart32": "aten_norm_part", "KAtenRec": "aten_norm_rec", "KAtenScan": "aten_norm_scan",
+         "KAtenFinish": "aten_norm_finish",
          "KAtenWalk": "aten_norm_walk", "KAtenWalkC": "aten_norm_walk", "KClassEmf": "class_norm_stats"}
 
 
-def main():
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
+def aggregate(fetch, write):
+    """per kernel name: launches, HBM bytes fetched / written (corrected as the module docstring says) and per launch"""
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
@@ -60,6 +61,13 @@ def main():
         rec["write_bytes"] += w * 1024.0
     for rec in out.values():
         rec["hbm_bytes_per_launch"] = (rec["fetch_bytes"] + rec["write_bytes"]) / rec["launches"]
+    return out
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = aggregate(fetch, write)
     printable = dict(out)
     if len(sys.argv) > 5:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
