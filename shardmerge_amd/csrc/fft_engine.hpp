@@ -11,6 +11,7 @@
 // by g++ for the CPU work-group emulator used by the "not gpu" tests
 // (tests/emul).  No torch, no rocFFT.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <type_traits>
 
@@ -28,6 +29,11 @@
 #define SM_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
 #define SM_OPAQUE(x) ((void)0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SM_LAUNDER(x) asm("" : "+v"(x))
+#else
+#define SM_LAUNDER(x) ((void)0)
 #endif
 // keep the instruction scheduler from interleaving independent butterflies: one
 // butterfly's temporaries die before the next one's are born (register pressure)
@@ -290,6 +296,137 @@ template <> struct Dft<28> {
     }
 };
 
+// ---- complex-packed arithmetic (PACK mode 2): one vf2 holds (re, im) of ONE value -------------
+// The pair-packed form above (two butterflies side by side) doubles the twiddle registers of a pass;
+// the 128-VGPR kernels (512/1024-thread work-groups) spill with it and ran on single floats.  Here the two
+// lanes of a packed op are the two COMPONENTS: a complex add is one v_pk_add_f32, a complex multiply
+// v_pk_mul_f32 + v_pk_fma_f32, a multiply by -i costs nothing (the consuming add swaps and negates
+// through op_sel / neg_lo / neg_hi) - half the instructions of the scalar form at ITS register count.
+// clang folds a pure lane swap into op_sel but not a swap with one lane negated: those three ops are
+// spelled out.
+SM_HD vf2 cx_mul(vf2 x, vf2 w) {                 // x * w
+#if defined(__HIP_DEVICE_COMPILE__)
+    const vf2 t = x * mk2(w.x, w.x);
+    vf2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(t));
+    return r;
+#else
+    const float tr = x.x * w.x, ti = x.y * w.x;
+    return mk2(std::fmaf(-x.y, w.y, tr), std::fmaf(x.x, w.y, ti));
+#endif
+}
+SM_HD vf2 cx_add_mi(vf2 a, vf2 b) {              // a + (-i) b = (a.re + b.im, a.im - b.re)
+#if defined(__HIP_DEVICE_COMPILE__)
+    vf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return mk2(a.x + b.y, a.y - b.x);
+#endif
+}
+SM_HD vf2 cx_sub_mi(vf2 a, vf2 b) {              // a - (-i) b = (a.re - b.im, a.im + b.re)
+#if defined(__HIP_DEVICE_COMPILE__)
+    vf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return mk2(a.x - b.y, a.y + b.x);
+#endif
+}
+// x * (c + i s), c and s compile-time constants (an SGPR pair on the device)
+SM_HD vf2 cx_mul_cs(vf2 x, float c, float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_fma(mk2(x.y, x.x), mk2(-s, s), x * c);
+#else
+    return mk2(std::fmaf(x.y, -s, x.x * c), std::fmaf(x.x, s, x.y * c));
+#endif
+}
+// x * W_M^E (M = 32 or 28; compile-time exponent)
+template <int E, int M>
+SM_HD vf2 cx_mul_w(vf2 x) {
+    constexpr int e = ((E % M) + M) % M;
+    if constexpr (e == 0) return x;
+    else if constexpr (4 * e == M) return cx_add_mi(vzero<vf2>(), x);          // * (-i)
+    else if constexpr (2 * e == M) return -x;
+    else if constexpr (4 * e == 3 * M) return cx_sub_mi(vzero<vf2>(), x);      // * (+i)
+    else if constexpr (M == 32) return cx_mul_cs(x, W32_RE[e], W32_IM[e]);
+    else return cx_mul_cs(x, W28_RE[e], W28_IM[e]);
+}
+
+template <int R> struct CDft;
+template <> struct CDft<1> { static SM_HD void run(vf2*) {} };
+template <> struct CDft<2> {
+    static SM_HD void run(vf2* z) { const vf2 a = z[0]; z[0] = a + z[1]; z[1] = a - z[1]; }
+};
+template <> struct CDft<4> {
+    static SM_HD void run(vf2* z) {
+        const vf2 t0 = z[0] + z[2], t1 = z[0] - z[2], t2 = z[1] + z[3], d = z[1] - z[3];
+        z[0] = t0 + t2; z[2] = t0 - t2;
+        z[1] = cx_add_mi(t1, d); z[3] = cx_sub_mi(t1, d);
+    }
+};
+// N = A*B Cooley-Tukey as DftComposite; M: the twiddle table's modulus (32 for the power-of-two sizes, 28 for 4 x 7)
+template <int A, int B, int M>
+struct CDftComposite {
+    static SM_HD void run(vf2* z) {
+        constexpr int N = A * B;
+        static_assert(M % N == 0, "twiddle table");
+        vf2 y[N];
+        static_for<0, B>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            vf2 t[A];
+            static_for<0, A>([&](auto a_) { constexpr int a = decltype(a_)::value; t[a] = z[B * a + b]; });
+            CDft<A>::run(t);
+            static_for<0, A>([&](auto k_) {
+                constexpr int k1 = decltype(k_)::value;
+                y[k1 * B + b] = cx_mul_w<(b * k1) * (M / N), M>(t[k1]);
+            });
+        });
+        static_for<0, A>([&](auto k_) {
+            constexpr int k1 = decltype(k_)::value;
+            vf2 t[B];
+            static_for<0, B>([&](auto b_) { constexpr int b = decltype(b_)::value; t[b] = y[k1 * B + b]; });
+            CDft<B>::run(t);
+            static_for<0, B>([&](auto k2_) { constexpr int k2 = decltype(k2_)::value; z[k1 + A * k2] = t[k2]; });
+        });
+    }
+};
+template <> struct CDft<8> { static SM_HD void run(vf2* z) { CDftComposite<2, 4, 32>::run(z); } };
+template <> struct CDft<16> { static SM_HD void run(vf2* z) { CDftComposite<4, 4, 32>::run(z); } };
+template <> struct CDft<32> { static SM_HD void run(vf2* z) { CDftComposite<4, 8, 32>::run(z); } };
+template <int P>
+struct CDftOdd {
+    static SM_HD void run(vf2* z) {
+        constexpr int H = (P - 1) / 2;
+        vf2 sm[H + 1], df[H + 1];
+        const vf2 x0 = z[0];
+        vf2 acc = x0;
+        static_for<1, H + 1>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            sm[j] = z[j] + z[P - j]; df[j] = z[j] - z[P - j];
+            acc = acc + sm[j];
+        });
+        z[0] = acc;
+        static_for<1, H + 1>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            vf2 pp = x0, qq = vzero<vf2>();
+            static_for<1, H + 1>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                constexpr float c = OddTab<P>::c((j * k) % P);
+                constexpr float s = OddTab<P>::s((j * k) % P);
+                pp = pp + sm[j] * c; qq = qq + df[j] * s;
+            });
+            z[k] = cx_add_mi(pp, qq); z[P - k] = cx_sub_mi(pp, qq);
+        });
+    }
+};
+template <> struct CDft<3> { static SM_HD void run(vf2* z) { CDftOdd<3>::run(z); } };
+template <> struct CDft<5> { static SM_HD void run(vf2* z) { CDftOdd<5>::run(z); } };
+template <> struct CDft<7> { static SM_HD void run(vf2* z) { CDftOdd<7>::run(z); } };
+template <> struct CDft<11> { static SM_HD void run(vf2* z) { CDftOdd<11>::run(z); } };
+template <> struct CDft<13> { static SM_HD void run(vf2* z) { CDftOdd<13>::run(z); } };
+template <> struct CDft<28> { static SM_HD void run(vf2* z) { CDftComposite<4, 7, 28>::run(z); } };
+
 // radices the planner may use (keep in sync with plan_fft in smhip_host.cpp)
 #define SM_RADIX_SWITCH(r, ...)                                  \
     switch (r) {                                                 \
@@ -429,12 +566,72 @@ SM_HD void apply_twiddles(V* xr, V* xi, const cf2* tw, int kidx0, int kidx1) {
     });
 }
 
-template <int R, bool PACK = true>
+// the complex-packed form of apply_twiddles: the same table entries and the same products
+template <int R>
+SM_HD void apply_twiddles_cx(vf2* z, const cf2* tw, int kidx) {
+    constexpr int LOGR = R <= 2 ? 1 : R <= 4 ? 2 : R <= 8 ? 3 : R <= 16 ? 4 : 5;
+    constexpr int HALF = 1 << (LOGR - 1);
+    vf2 pw[LOGR];
+#pragma unroll
+    for (int b = 0; b < LOGR; ++b) {
+        if ((1 << b) < R) { const cf2 w = tw[kidx << b]; pw[b] = mk2(w.x, w.y); }
+        else pw[b] = mk2(1.f, 0.f);
+    }
+    vf2 lw[HALF];
+    lw[0] = mk2(1.f, 0.f);
+    static_for<1, HALF>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int top = (i >= 16) ? 4 : (i >= 8) ? 3 : (i >= 4) ? 2 : (i >= 2) ? 1 : 0;
+        constexpr int rest = i - (1 << top);
+        if constexpr (rest == 0) lw[i] = pw[top];
+        else lw[i] = cx_mul(lw[rest], pw[top]);
+    });
+    static_for<1, R>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr int lo = i & (HALF - 1);
+        if constexpr (lo != 0) z[i] = cx_mul(z[i], lw[lo]);
+        if constexpr (i >= HALF) z[i] = cx_mul(z[i], pw[LOGR - 1]);
+    });
+}
+
+// PACK: 0 - single floats; 1 - two butterflies of a thread side by side in a vf2; 2 - complex-packed (re, im)
+template <int R, int PACK = 1>
 SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const cf2* tw) {
     constexpr int MB = EMAX / R;
     const int nb = N / R;
     const int tstep = N / (Ns * R);
-    if constexpr (PACK && MB >= 2 && MB % 2 == 0 && R <= 16) {
+    if constexpr (PACK == 2) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int j = t + m * T;
+            if (j < nb) {
+                vf2 z[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    // (laundered: LLVM's VectorCombine widens "load float, insert at lane 0" into a <2 x float> load of
+                    //  the register array, which then stays in scratch memory)
+                    float a = xr[m * R + i], b = xi[m * R + i];
+                    SM_LAUNDER(a); SM_LAUNDER(b);
+                    z[i] = mk2(a, b);
+                }
+                if (Ns > 1) {
+                    const int k = j % Ns;
+                    if constexpr (R <= 32 && R != 28) {
+                        apply_twiddles_cx<R>(z, tw, k * tstep);
+                    } else {
+#pragma unroll
+                        for (int i = 1; i < R; ++i) {
+                            const cf2 w = tw[i * k * tstep];
+                            z[i] = cx_mul(z[i], mk2(w.x, w.y));
+                        }
+                    }
+                }
+                CDft<R>::run(z);
+#pragma unroll
+                for (int i = 0; i < R; ++i) { xr[m * R + i] = z[i].x; xi[m * R + i] = z[i].y; }
+            }
+        }
+    } else if constexpr (PACK == 1 && MB >= 2 && MB % 2 == 0 && R <= 16) {
         // the thread's butterflies j = t + m*T go through the same arithmetic: two at a time,
         // side by side in the lanes of a vf2 (the second of a pair may lie beyond the last
         // butterfly: its lane computes on stale values that nobody stores)
@@ -474,7 +671,7 @@ SM_HD void pass_compute(float* xr, float* xi, int N, int Ns, int T, int t, const
                         }
                     }
                 }
-                if constexpr (R == 32 && !PACK) DftComposite<4, 8>::run(xr + m * R, xi + m * R);
+                if constexpr (R == 32 && PACK == 0) DftComposite<4, 8>::run(xr + m * R, xi + m * R);
                 else Dft<R>::run(xr + m * R, xi + m * R);
             }
         }
@@ -517,8 +714,8 @@ template <class P> SM_HD int plan_lds(const FftPlanDev& pl) { if constexpr (P::i
 //   fin_gather(tid, state, comp_c): read from LDS (natural order X[k]) what the
 //        storer needs of component comp.
 // State must expose float xr[EREG], xi[EREG].
-// PACK = false keeps every butterfly on single floats (the inverse column pass spills
-// registers with the paired form and loses more than the shorter instruction stream wins)
+// PACK (see pass_compute): 0 keeps every butterfly on single floats, 1 pairs a thread's butterflies (twice the twiddle
+// registers: the inverse column pass and the 128-VGPR row plans spill with it), 2 packs (re, im)
 // diagnostic builds (tools/build_variant.sh + tools/ab_kprof.sh): -DSM_DIAG_NOFFT=<mask> drops the radix passes of
 // the kernels whose bit is set (1 f1, 2 f2, 4 f2s, 8 i1, 16 i2): their memory traffic and ONE exchange remain
 #ifndef SM_DIAG_NOFFT
@@ -532,7 +729,7 @@ struct NoHook { template <class C> SM_HD void operator()(C) const {} };
 // j = t + m*T < N/R0): no natural scatter / first gather, nat_scatter is never called; bit 1 - the caller takes the
 // result in LAST-PASS layout (x[m*RL + i] = out[j + i*N/RL], j = t + m*T < N/RL): no final scatter / gather, fin_gather
 // is never called.  Each saves one of the transform's exchanges through LDS (two barriers and 2 x N dwords per component).
-template <class P, bool PACK = true, int DIAG = 0, int SKIPS = 0, class Ex, class StT, class NatScatter, class FinGather, class AfterNat = NoHook>
+template <class P, int PACK = 1, int DIAG = 0, int SKIPS = 0, class Ex, class StT, class NatScatter, class FinGather, class AfterNat = NoHook>
 SM_HD void wg_fft(Ex& ex, StT& st, const FftPlanDev& pl, float* lds, NatScatter nat_scatter, FinGather fin_gather, AfterNat after_nat = AfterNat{}) {
     using S = typename StT::value_type;
     const int N = plan_N<P>(pl), T = plan_T<P>(pl), LF = plan_lds<P>(pl);

@@ -263,8 +263,12 @@ template <class P> constexpr bool f1_full_batch() {
 template <class P> constexpr bool f1_opaque() {
     if constexpr (P::is_static) return P::T >= 512; else return false;
 }
-template <class P> constexpr bool f1_pack() {
-    if constexpr (P::is_static) return P::T <= SM_ROW_PACK_MAX_T; else return true;
+// ... (PACK mode of wg_fft: 0 single floats, 1 paired butterflies, 2 complex-packed - the scalar form's register count)
+#ifndef SM_ROW_PACK_BIG
+#define SM_ROW_PACK_BIG 0
+#endif
+template <class P> constexpr int f1_pack() {
+    if constexpr (P::is_static) return P::T <= SM_ROW_PACK_MAX_T ? 1 : SM_ROW_PACK_BIG; else return 1;
 }
 
 template <class P, class Ex>
@@ -564,7 +568,7 @@ SM_HD void k_f1(Ex& ex, const F1Params& p) {
 #define SM_F1Q_PREFETCH_B 1     // issue the second operand's loads before the first exchange (measured: -2..5 %)
 #endif
 #ifndef SM_F1Q_PACK
-#define SM_F1Q_PACK true
+#define SM_F1Q_PACK 1
 #endif
 template <class P> constexpr bool f1q_eligible() {
     if constexpr (P::is_static) return 4 * P::T <= 1024 && (P::N / P::T) % 2 == 0 && P::N % 8 == 0; else return false;
@@ -911,7 +915,10 @@ SM_HD void k_f2(Ex& ex, const F2Params& p) {
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
-    wg_fft<P, true, 2>(ex, st, pl, lds,
+#ifndef SM_F2_PACK
+#define SM_F2_PACK 1
+#endif
+    wg_fft<P, SM_F2_PACK, 2>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
@@ -1180,7 +1187,10 @@ SM_HD void k_f2s(Ex& ex, const F2SParams& p) {
         if (p.hist) for (int h = tid; h < HIST1_BINS; h += nthreads) lhist[h] = 0;
     });
 
-    wg_fft<P, true, 4, DIRECT>(ex, st, pl, lds,
+#ifndef SM_F2S_PACK
+#define SM_F2S_PACK 1
+#endif
+    wg_fft<P, SM_F2S_PACK, 4, DIRECT>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const float* x = comp_of<comp>(s);
@@ -1409,7 +1419,10 @@ SM_HD void k_i1(Ex& ex, const I1Params& p) {
         }
     });
 
-    wg_fft<P, false, 8>(ex, st, pl, lds,
+#ifndef SM_I1_PACK
+#define SM_I1_PACK 0
+#endif
+    wg_fft<P, SM_I1_PACK, 8>(ex, st, pl, lds,
         [&](int tid, FftState& s, auto comp_c) {
             constexpr int comp = decltype(comp_c)::value;
             const int g = tid / T, t = tid % T;
@@ -1935,7 +1948,16 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
     // The stream is cut into rounds of ROUND steps; after each round the staged candidates go
     // to the global lists, so a work-group's staging area only has to hold one round's worth
     // (a 235 M-element tensor used to overflow it - and redo the whole layer in safe mode)
-    constexpr int ROUND = 16;
+#ifndef SM_SEL_ROUND
+#define SM_SEL_ROUND 16
+#endif
+#ifndef SM_SEL_U
+#define SM_SEL_U 4
+#endif
+#ifndef SM_DIAG_SEL
+#define SM_DIAG_SEL 0          // diagnostic builds: bit 0 drops the staging path, bit 1 the sums
+#endif
+    constexpr int ROUND = SM_SEL_ROUND;
     ex.each(st, [&](int, EmptyState& s) { s.red[0] = s.red[1] = s.red[2] = s.red[3] = 0.0; });
     for (int r0 = 0; r0 < p.chunks; r0 += ROUND) {
     const int r1 = (r0 + ROUND < p.chunks) ? r0 + ROUND : p.chunks;
@@ -1957,37 +1979,64 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
                 else for (int e = 0; e < n; ++e) p.blendR[i0 + e] = rr[e];
                 a = rr;
             }
+            // keys of the selected level-1 bin: lo <= key < lo + 2^20, i.e. (key - lo) < 2^20 unsigned; above it: key >= hi
+            // (prefix 0xffffffff - no guess - gives lo = 0xfff00000, which no 31-bit key reaches from either side)
+            const uint32_t lo = prefix << 20, hi = lo + (1u << 20);
+            const bool has_hi = prefix < 2047u;
+            uint32_t ka[4], kb[4], wv[4];
+            bool hit = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (e < n) {
-                    const uint32_t w = uniform_w ? w0 : weight_at(wr, i0 + e);
-                    const uint32_t ka = f2u(a[e]) & 0x7fffffffu;
-                    if constexpr (BLEND) ex.lds_atomic_add(&lh1[ka >> 20], w);
-                    if ((ka >> 20) == prefix) {
-                        ex.lds_atomic_add(&lh[(ka >> 10) & 1023u], w);
-                        const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
-                        if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = ka | ((w - 1u) << 31);
-                    } else if (p.sumsq && (ka >> 20) > prefix) {
-                        q00 += (float)w * a[e] * a[e];
-                    }
-                    if (hasY) {
-                        const uint32_t kb = f2u(b[e]) & 0x7fffffffu;
-                        const uint32_t binb = kb >> 20;
-                        if (binb == prefix) {
-                            ex.lds_atomic_add(&lh[(kb >> 10) & 1023u], w);
+                wv[e] = (e < n) ? (uniform_w ? w0 : weight_at(wr, i0 + e)) : 0u;
+                ka[e] = f2u(a[e]) & 0x7fffffffu;
+                kb[e] = hasY ? (f2u(b[e]) & 0x7fffffffu) : 0u;
+                hit = hit || ((e < n) && ((ka[e] - lo) < (1u << 20) || (hasY && (kb[e] - lo) < (1u << 20))));
+            }
+            if constexpr (BLEND) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < n) ex.lds_atomic_add(&lh1[ka[e] >> 20], wv[e]);
+            }
+            // The bin holds a few per cent of the elements: one test per quad, the staging work behind it
+            if (hit && !(SM_DIAG_SEL & 1)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < n) {
+                        const uint32_t w = wv[e];
+                        if ((ka[e] - lo) < (1u << 20)) {
+                            ex.lds_atomic_add(&lh[(ka[e] >> 10) & 1023u], w);
                             const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
-                            if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = kb | ((w - 1u) << 31);
+                            if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = ka[e] | ((w - 1u) << 31);
                         }
-                        if (p.fuse_reduce && same_sign(a[e], b[e])) {
-                            if (binb > prefix) {            // |r1| >= threshold whatever its low bits
-                                const float wf = (float)w;
-                                q00 += wf * a[e] * a[e]; q01 += wf * a[e] * b[e]; q11 += wf * b[e] * b[e]; qc += wf;
-                            } else if (binb == prefix) {
-                                const uint32_t pos = ex.lds_atomic_add_ret(&lctl[1], 1u);
-                                if (pos < (uint32_t)STAGE_PAIRS) { cf4 v = {a[e], b[e], (float)w, 0.f}; lpairs[pos] = v; }
+                        if (hasY && (kb[e] - lo) < (1u << 20)) {
+                            ex.lds_atomic_add(&lh[(kb[e] >> 10) & 1023u], w);
+                            const uint32_t pos = ex.lds_atomic_add_ret(&lctl[0], 1u);
+                            if (pos < (uint32_t)STAGE_KEYS) lkeys[pos] = kb[e] | ((w - 1u) << 31);
+                            if (p.fuse_reduce && same_sign(a[e], b[e])) {
+                                const uint32_t pp = ex.lds_atomic_add_ret(&lctl[1], 1u);
+                                if (pp < (uint32_t)STAGE_PAIRS) { cf4 v = {a[e], b[e], (float)w, 0.f}; lpairs[pp] = v; }
                             }
                         }
                     }
+                }
+            }
+            // the sums over what lies ABOVE the bin (it survives whatever the threshold's low bits): branch-free, a value
+            // outside the class enters as an exact zero
+            if (p.sumsq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = (e < n) && has_hi && ka[e] >= hi;
+                    const float av = in ? a[e] : 0.f;
+                    q00 += ((float)wv[e] * av) * av;
+                }
+            }
+            if (hasY && p.fuse_reduce && !(SM_DIAG_SEL & 2)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = (e < n) && has_hi && kb[e] >= hi && same_sign(a[e], b[e]);   // |r1| >= threshold whatever its low bits
+                    const float wf = (float)wv[e];
+                    const float av = in ? a[e] : 0.f, bv = in ? b[e] : 0.f;
+                    const float wa = wf * av;
+                    q00 += wa * av; q01 += wa * bv; q11 += (wf * bv) * bv; qc += in ? wf : 0.f;
                 }
             }
             s00 += q00; s01 += q01; s11 += q11; cnt += qc;
@@ -1995,7 +2044,7 @@ SM_HD void k_select2(Ex& ex, const Select2Params& p) {
         if (p.vec4) {
             // 16-byte loads, U steps in flight together: the address is clamped instead of
             // branched around so that the loads issue back to back
-            constexpr int U = 4;
+            constexpr int U = SM_SEL_U;
             const cf4* X4 = (const cf4*)p.X;
             const cf4* Y4 = (const cf4*)(BLEND ? p.blendB : p.Y);
             for (int c0 = r0; c0 < r1; c0 += U) {

@@ -2033,7 +2033,10 @@ class Pipeline {
         }
         noise_seed_ = noise_seed_base;           // the noise model is a function of (layer step, bin): runs repeat bit for bit
         int step = 0;
-        int round_idx = 0;                       // tournament round: the cull fraction (and its speculation slot) goes with it
+        int round_idx = 0;                       // tournament round: the cull fraction goes with it
+        int pair_idx = 0;                        // pair merge of this layer, in order: its speculation slot (one guess per
+                                                 // (round, position): two pairs of one round have different thresholds - with
+                                                 // one guess per round a K = 4 layer missed 22 % of its speculations)
         int deferred_step = -1;
         bool deferred_cut = false, deferred_cull = false;
         while (stack.size() > 1) {
@@ -2194,7 +2197,7 @@ class Pipeline {
                         const bool fused_norm = im_parts > 0 && !safe_select && cull_pct > 0;
                         if (fused1d) have_cull = cull_pct > 0;
                         else spectral_blend(g, BLEND_SLERP, t, d.t_sum, d.cutoff_pct, cull_pct, 1, true, have_cull,
-                                            fused_norm ? &sel_parts : nullptr, std::min(round_idx, 6));
+                                            fused_norm ? &sel_parts : nullptr, std::min(pair_idx++, 6));
                         for (int side = 0; side < 2; ++side) {          // consumed spectral inputs give their planes back
                             Slot& in = side == 0 ? stack[x] : stack[y];
                             if (in.spectral) { pool_release(in.re_id); pool_release(in.im_id); in.re_id = in.im_id = -1; }
