@@ -14,9 +14,19 @@ def build(force: bool = False) -> Path:
     srcs = [HERE / "smhip_emul.cpp"] + sorted(CSRC.glob("*.hpp")) + sorted(CSRC.glob("*.inc")) + \
            [HERE.parents[1] / "include" / "shardmerge_hip.h"]
     newest = max(p.stat().st_mtime for p in srcs)
-    if force or not SO.exists() or SO.stat().st_mtime < newest:
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas",
-                        "-Wno-unused-variable", str(HERE / "smhip_emul.cpp"), "-o", str(SO)], check=True)
+    stale = lambda: force or not SO.exists() or SO.stat().st_mtime < newest
+    if stale():
+        # several pytest-xdist workers may get here together: one builds (into a temporary name, renamed when
+        # complete), the others wait for the lock and find the library fresh
+        import fcntl
+        import os
+        with open(HERE / ".build.lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                tmp = SO.with_suffix(f".so.{os.getpid()}.tmp")
+                subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unknown-pragmas",
+                                "-Wno-unused-variable", str(HERE / "smhip_emul.cpp"), "-o", str(tmp)], check=True)
+                os.replace(tmp, SO)
     return SO
 
 
