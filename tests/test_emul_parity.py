@@ -156,6 +156,25 @@ def test_static_and_dynamic_plan_lengths(engine, n):
 TOL_FFT = 3e-6
 
 
+def test_complex_packed_engine_mode(golden):
+    """fft_engine.hpp's PACK mode 2 (one vf2 = re, im of one value; off by default - measured on MI355X: the same
+    kernel times, profiles/r04_ab_complex_packed_butterflies.txt) is the same transform: every radix through the row,
+    column and inverse kernels of an alternate emulator build, and a golden layer through the whole pipeline.  (The
+    device spelling of its three swizzled ops is checked on the GPU by tools/cx_ops_check.hip.)"""
+    from oracle import spectral_oracle as so
+    from tests.emul.loader import emul_engine_variant
+    eng = emul_engine_variant(["-DSM_ROW_PACK_BIG=2", "-DSM_I1_PACK=2", "-DSM_F1Q_PACK=2", "-DSM_F2_PACK=2", "-DSM_F2S_PACK=2",
+                               "-DSM_ROW_PACK_MAX_T=0"], "cpx")
+    for n in (8192, 14336, 7168, 3072, 5120, 13824, 2304, 1408):      # radices 32 16 8 7 4 3 5; 1408 = 11 * 128 at run time
+        g = torch.Generator().manual_seed(n)
+        for shape in [(2, n), (n, 2)]:
+            x = torch.randn(*shape, generator=g)
+            f = eng.fft_transform(x)
+            assert so.rel_err(torch.view_as_real(f), torch.view_as_real(so.fft_transform(x))) < TOL_FFT
+            assert so.rel_err(eng.ifft_transform(f), x) < TOL_FFT
+    pc.check_layer(eng, golden, gi.LAYER_CASES[0])
+
+
 def test_misaligned_inputs_take_the_elementwise_path(engine):
     """Static-plan lengths assume 16-byte aligned rows; an unaligned view must fall back
     to the run-time kernel and give the same answer."""
