@@ -166,6 +166,20 @@ int smhip_merge_layer(smhip_ctx* ctx, const smhip_layer_desc* desc, void* out_bf
 int smhip_addition_merge(smhip_ctx* ctx, int k, const void* const* finetunes, const void* base, int dtype, size_t n,
                          int sign_agreement, void* out, void* stream);
 
+/* ---- slerp (reference shard/tensor/functions.py:24-43) on fp32 device tensors of rows x cols elements (1-D:
+ *      rows = 1): the cosine is taken between the UN-normalised vectors over the whole tensor, the relative vector
+ *      v1 - v0 dot is normalised along the LAST dimension (F.normalize(dim=-1), eps 1e-12), out = v0 cos + rel sin.
+ *      rows * cols = 0: nothing to do.  A zero vector gives NaN, as in the reference. ---- */
+int smhip_slerp(smhip_ctx* ctx, const float* v0, const float* v1, size_t rows, size_t cols, float t, float* out, void* stream);
+
+/* ---- the two halves of normalize_tensor (functions.py:75-88: norm = tensor.norm().item(); tensor / norm):
+ *      smhip_exact_norm - ||x||_2 accumulated in fp64 (the norm as torch.norm computes it on CPU, rounding bias
+ *      included, is smhip_reference_cpu_norm); norm_out: HOST double.
+ *      smhip_div_scalar - out = x / s in x's dtype (a 16-bit tensor over a Python float: an fp32 division rounded
+ *      to the dtype, as torch does it); out may be x. ---- */
+int smhip_exact_norm(smhip_ctx* ctx, const void* x, int dtype, size_t n, double* norm_out, void* stream);
+int smhip_div_scalar(smhip_ctx* ctx, const void* x, int dtype, size_t n, float s, void* out, void* stream);
+
 /* ---- correlate_pairs (reference shard/tensor/functions.py:304-314, the legacy fourier.py operator's
  *      pairing matrix): matrix[i][j] = mean over the trailing positions of
  *      cosine_similarity(t_i, t_j, dim=0).nan_to_num(0); zero diagonal.  tensors: k (2..8) device

@@ -100,6 +100,9 @@ class SmhipLibrary:
         d.smhip_addition_merge.argtypes = [P, I, C.POINTER(C.c_void_p), P, I, C.c_size_t, I, P, P]
         d.smhip_correlate_pairs.argtypes = [P, I, C.POINTER(C.c_void_p), I, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), P]
         d.smhip_reference_cpu_norm.argtypes = [P, P, P, I, C.c_size_t, C.POINTER(C.c_float), P]
+        d.smhip_slerp.argtypes = [P, P, P, C.c_size_t, C.c_size_t, C.c_float, P, P]
+        d.smhip_exact_norm.argtypes = [P, P, I, C.c_size_t, C.POINTER(D), P]
+        d.smhip_div_scalar.argtypes = [P, P, I, C.c_size_t, C.c_float, P, P]
         d.smhip_debug_option.argtypes = [P, C.c_char_p, C.c_long]
         d.smhip_debug_query.argtypes = [P, C.c_char_p, C.POINTER(C.c_long)]
         d.smhip_profile_enable.argtypes = [P, I]

@@ -77,6 +77,21 @@ SM_HD uint32_t pack_bf16x2(float a, float b) {
     return (uint32_t)f_to_bf16(a) | ((uint32_t)f_to_bf16(b) << 16);
 #endif
 }
+// a ROUNDED fp32 product / sum (the device compiler contracts a * b + c into an fma otherwise)
+SM_HD float aten_fmul_(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = a * b; asm volatile("" : "+v"(r)); return r;
+#else
+    volatile float r = a * b; return r;
+#endif
+}
+SM_HD float aten_fadd_(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = a + b; asm volatile("" : "+v"(r)); return r;
+#else
+    volatile float r = a + b; return r;
+#endif
+}
 SM_HD bool is_nan(float v) { return v != v; }
 SM_HD bool is_inf(float v) { return (f2u(v) & 0x7fffffffu) == 0x7f800000u; }
 
@@ -3333,6 +3348,144 @@ SM_HD float round_to_dtype(float v, int dtype) {
     return f16_to_f(f_to_f16_any(v));
 }
 SM_HD float sign_of(float v) { return is_nan(v) ? v : (float)sgn(v); }      // torch.sign(NaN) = NaN
+
+// =====================================================================
+// A1 / A8 at function level (not on the merge's hot path - inside it both are fused into the kernels above):
+// slerp(v0, v1, t) (reference shard/tensor/functions.py:24-43) and tensor / norm (functions.py:75-88).
+//   dot   = clamp(sum(v0 v1) / (||v0|| ||v1||), -1, 1)        (quirk Q5: the cosine of the UN-normalised vectors)
+//   theta = acos(dot) t;  rel = v1 - v0 dot;  rel /= max(||rel||_2 along the LAST dim, 1e-12)   (F.normalize(dim=-1))
+//   out   = v0 cos(theta) + rel sin(theta)
+// Sums are taken in fp64 and rounded once (torch sums in fp32: the two agree to a few 1e-8), the element-wise
+// part is torch's sequence of fp32 operations.
+// =====================================================================
+struct FnSumsParams { const float* v0; const float* v1; size_t n; int chunks; double* partials; };   // [grid][4]
+template <class Ex>
+SM_HD void k_fn_sums(Ex& ex, const FnSumsParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double s01 = 0, s00 = 0, s11 = 0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t i = start + (size_t)c * nt + tid;
+            if (i >= p.n) break;
+            const double a = (double)p.v0[i], b = (double)p.v1[i];
+            s01 += a * b; s00 += a * a; s11 += b * b;
+        }
+        s.red[0] = s01; s.red[1] = s00; s.red[2] = s11; s.red[3] = 0.0;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        for (int q = 0; q < 4; ++q) p.partials[4 * (size_t)ex.bid() + q] = tot[q];
+    });
+}
+SM_HD float fn_acosf(float x) { return acosf(x); }
+struct FnSlerpFinParams { const double* partials; int nparts; float t; float* consts; };    // consts: dot, cos(theta), sin(theta), -
+template <class Ex>
+SM_HD void k_fn_slerp_fin(Ex& ex, const FnSlerpFinParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double a = 0, b = 0, c = 0;
+        for (int i = tid; i < p.nparts; i += nt) { a += p.partials[4 * i]; b += p.partials[4 * i + 1]; c += p.partials[4 * i + 2]; }
+        s.red[0] = a; s.red[1] = b; s.red[2] = c; s.red[3] = 0.0;
+    });
+    ex.template block_sum<4>(st, [&](const double* tot) {
+        // (0 / 0 = NaN for a zero vector, as in the reference: clamp keeps NaN)
+        float dot = (float)tot[0] / ((float)sqrt(tot[1]) * (float)sqrt(tot[2]));
+        if (dot < -1.f) dot = -1.f;
+        if (dot > 1.f) dot = 1.f;
+        const float theta = fn_acosf(dot) * p.t;
+        p.consts[0] = dot; p.consts[1] = cosf(theta); p.consts[2] = sinf(theta); p.consts[3] = 0.f;
+    });
+}
+// one work-group per (row, column segment).  PHASE 0: sum of rel^2 of the segment -> part[row * cchunks + seg];
+// PHASE 1: the outputs
+struct FnSlerpRowsParams {
+    const float* v0; const float* v1; float* out;
+    size_t rows, cols;
+    int cchunks, seg;               // segments per row, elements per segment
+    const float* consts;
+    double* part;                   // [rows * cchunks]
+    const float* den;               // [rows]: max(||rel row||, 1e-12)
+};
+template <int PHASE, class Ex>
+SM_HD void k_fn_slerp_rows(Ex& ex, const FnSlerpRowsParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    const size_t row = (size_t)ex.bid() / p.cchunks;
+    const int sg = (int)((size_t)ex.bid() % p.cchunks);
+    const float dot = p.consts[0], ct = p.consts[1], sn = p.consts[2];
+    const size_t c0 = (size_t)sg * p.seg, c1 = (c0 + p.seg < p.cols) ? c0 + p.seg : p.cols;
+    const float dn = PHASE == 1 ? p.den[row] : 1.f;
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double acc = 0.0;
+        for (size_t c = c0 + tid; c < c1; c += nt) {
+            const size_t i = row * p.cols + c;
+            const float a = p.v0[i];
+            const float rel = aten_fadd_(p.v1[i], -aten_fmul_(a, dot));
+            if (PHASE == 0) acc += (double)rel * (double)rel;
+            else p.out[i] = aten_fadd_(aten_fmul_(a, ct), aten_fmul_(rel / dn, sn));
+        }
+        s.red[0] = acc;
+    });
+    if (PHASE == 0) ex.template block_sum<1>(st, [&](const double* tot) { p.part[row * p.cchunks + sg] = tot[0]; });
+}
+struct FnSlerpDenParams { const double* part; size_t rows; int cchunks; float* den; };
+template <class Ex>
+SM_HD void k_fn_slerp_den(Ex& ex, const FnSlerpDenParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t row = (size_t)ex.bid() * ex.nthreads() + tid;
+        if (row >= p.rows) return;
+        double a = 0.0;
+        for (int c = 0; c < p.cchunks; ++c) a += p.part[row * p.cchunks + c];
+        const float nrm = (float)sqrt(a);
+        p.den[row] = nrm > 1e-12f ? nrm : 1e-12f;
+    });
+}
+// sum of squares of a tensor of any dtype (the exact norm of normalize_tensor) -> partials [grid][2] (k_sum_partials' layout)
+struct SumsqAnyParams { const void* x; int dtype; size_t n; int chunks; double* partials; };
+template <class Ex>
+SM_HD void k_sumsq_any(Ex& ex, const SumsqAnyParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState& s) {
+        double a = 0.0;
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t i = start + (size_t)c * nt + tid;
+            if (i >= p.n) break;
+            const double v = (double)load_elem(p.x, p.dtype, i);
+            a += v * v;
+        }
+        s.red[0] = a; s.red[1] = 0.0;
+    });
+    ex.template block_sum<2>(st, [&](const double* tot) { p.partials[2 * (size_t)ex.bid()] = tot[0]; p.partials[2 * (size_t)ex.bid() + 1] = tot[1]; });
+}
+// out = x / s in x's dtype: a 16-bit tensor divided by a Python float is an fp32 division rounded to the dtype
+struct DivScalarParams { const void* x; void* out; int dtype; size_t n; float s; int chunks; };
+template <class Ex>
+SM_HD void k_div_scalar(Ex& ex, const DivScalarParams& p) {
+    typename Ex::template State<EmptyState> st;
+    ex.init(st);
+    const int nt = ex.nthreads();
+    ex.each(st, [&](int tid, EmptyState&) {
+        const size_t start = (size_t)ex.bid() * p.chunks * nt;
+        for (int c = 0; c < p.chunks; ++c) {
+            const size_t i = start + (size_t)c * nt + tid;
+            if (i >= p.n) break;
+            const float v = load_elem(p.x, p.dtype, i) / p.s;
+            if (p.dtype == DT_F32) ((float*)p.out)[i] = v;
+            else if (p.dtype == DT_BF16) ((uint16_t*)p.out)[i] = f_to_bf16_any(v);
+            else ((uint16_t*)p.out)[i] = f_to_f16_any(v);
+        }
+    });
+}
 
 constexpr int ADD_MAX_MODELS = 16;
 struct AdditionParams {

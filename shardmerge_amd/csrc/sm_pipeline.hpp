@@ -179,6 +179,13 @@ SM_KERNEL_TAG(KSplit, SplitParams, "split_complex", k_split(ex, p))
 SM_KERNEL_TAG(KJoin, JoinParams, "join_complex", k_join(ex, p))
 SM_KERNEL_TAG(KCull, CullParams, "cull_inplace", k_cull(ex, p))
 SM_KERNEL_TAG(KAddition, AdditionParams, "addition_merge", k_addition(ex, p))
+SM_KERNEL_TAG(KFnSums, FnSumsParams, "fn_slerp_sums", k_fn_sums(ex, p))
+SM_KERNEL_TAG(KFnSlerpFin, FnSlerpFinParams, "fn_slerp_consts", k_fn_slerp_fin(ex, p))
+SM_KERNEL_TAG(KFnSlerpRows0, FnSlerpRowsParams, "fn_slerp_relnorm", k_fn_slerp_rows<0>(ex, p))
+SM_KERNEL_TAG(KFnSlerpRows1, FnSlerpRowsParams, "fn_slerp_out", k_fn_slerp_rows<1>(ex, p))
+SM_KERNEL_TAG(KFnSlerpDen, FnSlerpDenParams, "fn_slerp_den", k_fn_slerp_den(ex, p))
+SM_KERNEL_TAG(KSumsqAny, SumsqAnyParams, "fn_sumsq", k_sumsq_any(ex, p))
+SM_KERNEL_TAG(KDivScalar, DivScalarParams, "fn_div_scalar", k_div_scalar(ex, p))
 SM_KERNEL_TAG(KCorrPartial, CorrPartialParams, "correlate_pairs", k_corr_partial(ex, p))
 SM_KERNEL_TAG(KCorrFinish, CorrFinishParams, "correlate_finish", k_corr_finish(ex, p))
 SM_KERNEL_TAG(KSerialNorm, SerialNormParams, "serial_norm", k_serial_norm(ex, p))
@@ -211,7 +218,7 @@ SM_KERNEL_TAG_LB(KAtenFinish, AtenFinishParams, "aten_norm_finish", k_aten_finis
 #define SM_SIDE_KERNELS_1(X) X(KF2R1) X(KI1R1) X(KPublish) X(KHist) X(KScan) X(KSelect2) X(KSelect2Cull) X(KBlendSel) \
     X(KSpecCheck) X(KSelect3) X(KReduceCand) X(KReduce) X(KSlerpConsts) X(KSumPartials) X(KClassEmf)
 #define SM_SIDE_KERNELS_2(X) X(KDeltaNorms) X(KSumPartialsN) X(KBlend) X(KCombine) X(KExpand) X(KPack) X(KSplit) X(KJoin) \
-    X(KCull) X(KAddition) X(KCorrPartial) X(KCorrFinish) X(KSerialNorm) X(KSpecNorm) X(KSumsqCand) X(KSumSpec)       \
+    X(KCull) X(KAddition) X(KFnSums) X(KFnSlerpFin) X(KFnSlerpRows0) X(KFnSlerpRows1) X(KFnSlerpDen) X(KSumsqAny) X(KDivScalar) X(KCorrPartial) X(KCorrFinish) X(KSerialNorm) X(KSpecNorm) X(KSumsqCand) X(KSumSpec)       \
     X(KSpecRescale) X(KDftp) X(KDftpPairs) X(KTranspose)
 #define SM_SIDE_GROUPS 7         // groups 3 - 6: the run-time planned (DynPlan) transform kernels
 
@@ -2310,6 +2317,63 @@ class Pipeline {
         a.vec8 = (n % 8 == 0) && al;
         a.chunks = pick_chunks((n + 7) / 8, 256, 2, 8);
         be.template launch<KAddition>(stream_grid((n + 7) / 8, 256, a.chunks), 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        return SMHIP_OK;
+    }
+
+    // ---- function level: slerp (functions.py:24-43), tensor / scalar and the exact norm (functions.py:75-88) ----
+    int fn_slerp(const float* v0, const float* v1, size_t rows, size_t cols, float t, float* out) {
+        const size_t n = rows * cols;
+        if (n == 0) return SMHIP_OK;
+        int rc;
+        if (!small_.p && (rc = reserve(1, 1))) return rc;
+        const int seg = 256 * 64;
+        const size_t cch = (cols + seg - 1) / seg;
+        if (rows * cch > (size_t)1 << 30) return fail(SMHIP_ERR_ARG, "slerp: tensor too large");
+        FnSumsParams a;
+        a.v0 = v0; a.v1 = v1; a.n = n; a.chunks = pick_chunks(n, 256, 2, 8);
+        const int grid = stream_grid(n, 256, a.chunks);
+        if ((rc = ensure(tmpA_, ((size_t)grid * 4 + rows * cch) * sizeof(double) + (rows + 4) * sizeof(float)))) return rc;
+        a.partials = (double*)tmpA_.p;
+        double* part = a.partials + (size_t)grid * 4;
+        float* den = (float*)(part + rows * cch);
+        float* consts = den + rows;
+        be.template launch<KFnSums>(grid, 256, LDS_SCRATCH_FLOATS * 4, a, stream);
+        FnSlerpFinParams f;
+        f.partials = a.partials; f.nparts = grid; f.t = t; f.consts = consts;
+        be.template launch<KFnSlerpFin>(1, 256, LDS_SCRATCH_FLOATS * 4, f, stream);
+        FnSlerpRowsParams r;
+        r.v0 = v0; r.v1 = v1; r.out = out; r.rows = rows; r.cols = cols; r.cchunks = (int)cch; r.seg = seg;
+        r.consts = consts; r.part = part; r.den = den;
+        be.template launch<KFnSlerpRows0>((int)(rows * cch), 256, LDS_SCRATCH_FLOATS * 4, r, stream);
+        FnSlerpDenParams d;
+        d.part = part; d.rows = rows; d.cchunks = (int)cch; d.den = den;
+        be.template launch<KFnSlerpDen>((int)((rows + 255) / 256), 256, LDS_SCRATCH_FLOATS * 4, d, stream);
+        be.template launch<KFnSlerpRows1>((int)(rows * cch), 256, LDS_SCRATCH_FLOATS * 4, r, stream);
+        return SMHIP_OK;
+    }
+    int fn_div_scalar(const void* x, int dtype, size_t n, float s, void* out) {
+        if (n == 0) return SMHIP_OK;
+        DivScalarParams q;
+        q.x = x; q.out = out; q.dtype = dtype; q.n = n; q.s = s; q.chunks = pick_chunks(n, 256, 2, 8);
+        be.template launch<KDivScalar>(stream_grid(n, 256, q.chunks), 256, LDS_SCRATCH_FLOATS * 4, q, stream);
+        return SMHIP_OK;
+    }
+    int fn_exact_norm(const void* x, int dtype, size_t n, double* norm_out) {
+        *norm_out = 0.0;
+        if (n == 0) return SMHIP_OK;
+        int rc;
+        if (!small_.p && (rc = reserve(1, 1))) return rc;
+        SumsqAnyParams q;
+        q.x = x; q.dtype = dtype; q.n = n; q.chunks = pick_chunks(n, 256, 2, 8);
+        const int grid = stream_grid(n, 256, q.chunks);
+        if ((rc = ensure(tmpA_, (size_t)grid * 2 * sizeof(double)))) return rc;
+        q.partials = (double*)tmpA_.p;
+        be.template launch<KSumsqAny>(grid, 256, LDS_SCRATCH_FLOATS * 4, q, stream);
+        SumPartialsParams sp;
+        sp.partials = q.partials; sp.nparts = grid; sp.out = mail_->norm2;
+        be.template launch<KSumPartials>(1, 256, LDS_SCRATCH_FLOATS * 4, sp, stream);
+        be.sync(stream);
+        *norm_out = std::sqrt(mail_->norm2[0]);
         return SMHIP_OK;
     }
 

@@ -207,6 +207,50 @@ class Engine:
                                                          _DTYPE_CODE[dtype], xs.numel(), C.byref(out), self._stream()))
         return float(out.value)
 
+    # -- A1 / A8 at function level ----------------------------------------------------------------
+    def slerp(self, v0: torch.Tensor, v1: torch.Tensor, t: float) -> torch.Tensor:
+        """reference functions.py:24-43 (quirk Q5 kept); the relative vector is normalised along the last dimension."""
+        if v0.shape != v1.shape:
+            raise ValueError(f"shape mismatch: {tuple(v0.shape)} vs {tuple(v1.shape)}")
+        a, b = self._dev(v0, torch.float32), self._dev(v1, torch.float32)
+        out = torch.empty_like(a)
+        cols = a.shape[-1] if a.dim() >= 1 else 1
+        rows = a.numel() // cols if cols else 0
+        self._call(self.lib.dll.smhip_slerp(self.ctx.h, a.data_ptr(), b.data_ptr(), rows, cols if a.numel() else 0, float(t),
+                                            out.data_ptr(), self._stream()))
+        return out
+
+    def exact_norm(self, x: torch.Tensor) -> float:
+        """||x||_2, accumulated in fp64 on the device"""
+        dtype = x.dtype if x.dtype in _DTYPE_CODE else torch.float32
+        xs = self._dev(x, dtype)
+        out = C.c_double(0.0)
+        self._call(self.lib.dll.smhip_exact_norm(self.ctx.h, xs.data_ptr(), _DTYPE_CODE[dtype], xs.numel(), C.byref(out), self._stream()))
+        return float(out.value)
+
+    def div_scalar(self, x: torch.Tensor, s: float) -> torch.Tensor:
+        """``x / s`` in x's dtype, as torch divides a tensor by a Python float (fp32 division, one rounding)"""
+        dtype = x.dtype if x.dtype in _DTYPE_CODE else torch.float32
+        xs = self._dev(x, dtype)
+        out = torch.empty_like(xs)
+        self._call(self.lib.dll.smhip_div_scalar(self.ctx.h, xs.data_ptr(), _DTYPE_CODE[dtype], xs.numel(), float(s), out.data_ptr(), self._stream()))
+        return out
+
+    def normalize_tensor(self, x: torch.Tensor, norm_mode: Optional[str] = None):
+        """reference functions.py:75-88: (x / norm, norm), norm = ``x.norm().item()`` - in ``reference_cpu`` mode the value
+        the reference's CPU run gets (ATen's biased fp32 kernel; a 16-bit tensor's norm is rounded to its dtype), else
+        the exact one.  norm == 0: x comes back unchanged."""
+        mode = DEFAULT_NORM_MODE if norm_mode is None else norm_mode
+        if mode not in NORM_MODES:
+            raise ValueError(f"norm_mode {mode!r}: one of {NORM_MODES}")
+        if mode == "reference_cpu":
+            norm = self.reference_cpu_norm(x)
+            if x.dtype in (torch.bfloat16, torch.float16):
+                norm = float(torch.tensor(norm, dtype=torch.float32).to(x.dtype))
+        else:
+            norm = self.exact_norm(x)
+        return (self.div_scalar(x, norm) if norm != 0 else self._dev(x, x.dtype if x.dtype in _DTYPE_CODE else torch.float32)), norm
+
     # -- N3: AdditionMerge / TaskAdditionMerge ---------------------------------------------
     def addition_merge(self, finetunes: Sequence[torch.Tensor], base: torch.Tensor, sign_agreement: bool = False) -> torch.Tensor:
         """sum_i (finetune_i - base) in the tensors' dtype, optionally masked by the majority sign

@@ -18,7 +18,7 @@ is another model than the one loaded; as in the reference.
 
 Every transform, blend and pairing matrix runs in the HIP library through the function-level C ABI
 (`smhip_merge_tensors_fft2_slerp`, `smhip_task_arithmetic_fft2`, `smhip_correlate_pairs`, `smhip_addition_merge`,
-`smhip_reference_cpu_norm`); torch is used for the handful of element-wise glue ops the reference itself does
+`smhip_reference_cpu_norm`, `smhip_div_scalar`); torch is used for the handful of element-wise glue ops the reference itself does
 between them (scale by target_norm, the add-back) on device tensors."""
 from __future__ import annotations
 
@@ -84,8 +84,8 @@ class LegacyFourierMerge(MergeTensorsBase):
         afterwards.  The fused `smhip_merge_tensors_fft2_slerp` normalises fp32 values by their exact norm, so the
         pair goes through the function-level transforms and blend instead (A4, A5-A7, A8)."""
         n0, n1 = self._norm(eng, v0), self._norm(eng, v1)
-        v0 = v0 / n0 if n0 != 0 else v0
-        v1 = v1 / n1 if n1 != 0 else v1
+        v0 = eng.div_scalar(v0, n0) if n0 != 0 else v0                      # (smhip_div_scalar: the tensors' dtype, one rounding)
+        v1 = eng.div_scalar(v1, n1) if n1 != 0 else v1
         if n1 < 1e-4 or n0 < 1e-4:
             return v0.float()
         f0, f1 = eng.fft_transform(v0.float()), eng.fft_transform(v1.float())

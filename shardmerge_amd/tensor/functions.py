@@ -4,8 +4,8 @@ names, argument order and error behaviour, computed by the HIP library.
 Differences a caller can see: results stay on the compute device (the reference
 moves every intermediate back to the CPU, functions.py:56-58), and ``device`` is
 only a hint - this build always computes on the MI355X.  ``slerp`` and
-``normalize_tensor`` are a handful of torch device ops (they are not on the hot
-path by themselves: inside the merge they are fused into the HIP kernels).
+``normalize_tensor`` have kernels of their own at this level (inside the merge they are
+fused into the transform and blend kernels).
 """
 from __future__ import annotations
 
@@ -16,21 +16,16 @@ import torch
 from ..engine import get_engine
 
 
-def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float) -> torch.Tensor:
+def slerp(v0: torch.Tensor, v1: torch.Tensor, t: float, device: str = "cuda") -> torch.Tensor:
     """reference functions.py:24-43 (quirk Q5 kept: cosine of un-normalised vectors,
-    unit-length relative vector)."""
-    dot = torch.clamp(torch.sum(v0 * v1) / (v0.norm() * v1.norm()), -1.0, 1.0)
-    theta = torch.acos(dot) * t
-    rel = torch.nn.functional.normalize(v1 - v0 * dot, dim=-1)
-    return v0 * torch.cos(theta) + rel * torch.sin(theta)
+    unit-length relative vector); ``smhip_slerp``."""
+    return get_engine(device).slerp(v0, v1, t)
 
 
 def normalize_tensor(tensor: torch.Tensor, device: str = "cuda") -> Tuple[torch.Tensor, float]:
-    """reference functions.py:75-88."""
-    eng = get_engine(device)
-    t = tensor.to(eng.device)
-    norm = t.double().pow(2).sum().sqrt().item()
-    return (t / norm if norm != 0 else t), norm
+    """reference functions.py:75-88: ``smhip_reference_cpu_norm`` (or ``smhip_exact_norm``: the engine's
+    norm_mode default decides) and ``smhip_div_scalar``."""
+    return get_engine(device).normalize_tensor(tensor)
 
 
 def fft_transform(tensor: torch.Tensor, device: str = "cuda") -> torch.Tensor:

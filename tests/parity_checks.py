@@ -393,3 +393,37 @@ def check_legacy(engine, golden, case):
     else:
         assert total <= 2.5 * floor + 1e-4, (total, floor)
     return total, resid, floor
+
+
+# ---- A1 / A8 at function level: smhip_slerp, smhip_exact_norm / smhip_reference_cpu_norm + smhip_div_scalar ----------
+def check_fn_slerp(engine, golden, case):
+    """functions.py:24-43 against the reference's own outputs (g3_slerp) and, on a 2-D tensor, against the oracle
+    (the relative vector is normalised along the LAST dimension there)"""
+    a, b = gi.pair_input(case)
+    out = engine.slerp(a, b, case["t"]).cpu()
+    assert so.rel_err(out, golden.get("g3_slerp.safetensors", case["id"])) < 2e-6
+    g = torch.Generator().manual_seed(case["seed"] + 1000)
+    x, y = torch.randn(37, 129, generator=g), torch.randn(37, 129, generator=g)
+    y = 0.6 * x + 0.8 * y
+    assert so.rel_err(engine.slerp(x, y, 0.35).cpu(), so.slerp(x, y, 0.35)) < 2e-6
+    e = torch.zeros(0)
+    assert engine.slerp(e, e, 0.5).numel() == 0
+
+
+def check_fn_normalize(engine):
+    """functions.py:75-88 as the reference's CPU run computes it: norm = tensor.norm().item() (a 16-bit tensor's norm is
+    a 16-bit value), tensor / norm in the tensor's dtype - bit for bit in reference_cpu mode; exact mode: the fp64 norm"""
+    g = torch.Generator().manual_seed(77)
+    for dtype, n in ((torch.float32, 8 * 1237), (torch.bfloat16, 8 * 4099), (torch.float16, 8 * 515)):
+        x = (torch.randn(n, generator=g) * 0.02).to(dtype)
+        out, norm = engine.normalize_tensor(x, norm_mode="reference_cpu")
+        ref_norm = x.norm().item()
+        assert norm == ref_norm, (dtype, norm, ref_norm)
+        assert torch.equal(out.cpu(), x / ref_norm), dtype
+        out_e, norm_e = engine.normalize_tensor(x, norm_mode="exact")
+        exact = x.double().pow(2).sum().sqrt().item()
+        assert abs(norm_e - exact) <= 1e-12 * exact
+        assert torch.equal(out_e.cpu(), x / exact)
+    z = torch.zeros(16)
+    out, norm = engine.normalize_tensor(z)
+    assert norm == 0.0 and torch.equal(out.cpu(), z)

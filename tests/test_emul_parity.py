@@ -24,6 +24,15 @@ def test_interpolate(engine, golden, case):
     pc.check_interp(engine, golden, case)
 
 
+@pytest.mark.parametrize("case", gi.SLERP_CASES, ids=lambda c: c["id"])
+def test_function_level_slerp(engine, golden, case):
+    pc.check_fn_slerp(engine, golden, case)
+
+
+def test_function_level_normalize_tensor(engine):
+    pc.check_fn_normalize(engine)
+
+
 @pytest.mark.parametrize("case", gi.PAIR_CASES, ids=lambda c: c["id"])
 def test_pair_slerp(engine, golden, case):
     pc.check_pair(engine, golden, case)
