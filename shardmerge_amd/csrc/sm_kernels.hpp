@@ -2519,7 +2519,10 @@ struct SlerpConstParams {
 // "class_norms" = 2) gives the same to 2e-6.
 constexpr int EMF_LEVELS = 16;
 constexpr int EMF_VALS = EMF_LEVELS + 2;        // weighted count, sum of squares, EMF_LEVELS sums of rounded squares
-constexpr int EMF_MAX_SAMPLE = 16;              // at most one piece of 8 rows (64 plane elements) in every 16 is read ...
+#ifndef SM_EMF_MAX_SAMPLE
+#define SM_EMF_MAX_SAMPLE 16
+#endif
+constexpr int EMF_MAX_SAMPLE = SM_EMF_MAX_SAMPLE;   // at most one piece of 8 rows (64 plane elements) in every 16 is read ...
 constexpr size_t EMF_MIN_SAMPLED = (size_t)2 << 20;   // ... as long as this many elements are
 struct ClassEmfParams {
     const float* reA; const float* reB;         // planes [Cb][R]

@@ -1274,7 +1274,7 @@ class Pipeline {
                 // levels reach 4 binades above that and 11 below (further down the sum loses nothing)
                 q.elo = (int)std::floor(std::log2(0.03 * (double)nfull + 1.0)) - 11;
                 q.sample = 1;
-                while (q.sample < EMF_MAX_SAMPLE && q.n / (2 * (size_t)q.sample) >= EMF_MIN_SAMPLED) q.sample *= 2;
+                while (q.sample < emf_max_sample && q.n / (2 * (size_t)q.sample) >= EMF_MIN_SAMPLED) q.sample *= 2;
                 const size_t rows = (q.n + 7) / 8, npieces = (rows + 8 * (size_t)q.sample - 1) / (8 * (size_t)q.sample);
                 q.iters = (int)std::max<size_t>(1, std::min<size_t>(64, (npieces + (size_t)32 * 384 - 1) / ((size_t)32 * 384)));   // ~384 work-groups: their
                                                                          // 36-value partials are summed by ONE work-group (k_slerp_consts)
@@ -1761,6 +1761,7 @@ class Pipeline {
     // and is joined before anything reads its result.  false: not started (the caller takes the synchronous path)
     void* aten_walk_pending_ = nullptr;
     bool aten_overlap = true;
+    int emf_max_sample = EMF_MAX_SAMPLE;   // k_class_emf reads at most one piece of 8 rows in this many (debug option "emf_max_sample")
     bool begin_delta_ref_norms(const std::vector<Slot>& stack, size_t n) {
         const int k = (int)stack.size();
         void* aux = aten_overlap && !aten_serial ? be.aux_stream() : nullptr;
